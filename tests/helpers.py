@@ -1,0 +1,61 @@
+"""Shared helpers for the parity tests (oracle side only)."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import hwgat_oracle as O
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_fixture(name):
+    return dict(np.load(os.path.join(GOLDEN, name)))
+
+
+def cfg_of(fx, **over):
+    T, nW, C, d0, nc, B, seed = [int(v) for v in fx["cfg"]]
+    cfg = dict(kp_dim=C, temporal_dim=T, num_classes=nc, embed_dim=d0,
+               depths=(2, 2, 4), ff_ratio=2.0, use_pe=True, num_kps=nW * 16, tp=2)
+    cfg.update(over)
+    return cfg, seed, B
+
+
+def oracle_from_fixture(fx, dtype=torch.float32):
+    cfg, seed, _ = cfg_of(fx)
+    wstd = float(fx["wstd"]) if "wstd" in fx else 0.08
+    params = {k: v.to(dtype) for k, v in O.synth_params(seed, weight_std=wstd, **cfg).items()}
+    model = O.OracleHWGAT(params, num_kps=cfg["num_kps"], temporal_dim=cfg["temporal_dim"])
+    return model, params, cfg
+
+
+def sub(t):
+    return t[:, ::5, ::3, ::7]
+
+
+def rel_err(a, b):
+    a = torch.as_tensor(a, dtype=torch.float64)
+    b = torch.as_tensor(b, dtype=torch.float64)
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def grad_digest_check(named_grads, fx, prefix, tol):
+    """compare {name: grad} with the `gh.`/`gn.` digests stored in a fixture"""
+    worst = 0.0
+    n = 0
+    for name, g in named_grads.items():
+        key = prefix + "gh." + name
+        if key not in fx:
+            continue
+        n += 1
+        gd = g.detach().double().flatten().cpu()
+        ref_norm, ref_sum = fx[prefix + "gn." + name]
+        scale = max(ref_norm, 1e-12)
+        e1 = abs(gd.norm().item() - ref_norm) / scale
+        e2 = (gd[:48] - torch.from_numpy(fx[key]).double()).norm().item() / \
+            max(np.linalg.norm(fx[key]), 1e-3 * scale / max(gd.numel(), 1) ** 0.5, 1e-30)
+        worst = max(worst, e1, e2)
+        assert e1 < tol, (name, "norm", e1)
+        assert e2 < tol * 10, (name, "head", e2)
+    assert n > 0
+    return worst
