@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Headline benchmark: HWGAT training step (fwd + loss + bwd + AdamW) clips/s.
+
+Workload = BASELINE.json configs[1]: B=64 clips per GPU, T=128 frames, J=67 raw
+joints -> 5 part windows (K=80), C=2, d_model=128, depths [2,2,4], 2002 classes,
+fp32, train mode with the reference defaults (dropout 0.1, stochastic attention
+drop).  Inputs are synthetic, resident in HBM before the timed region.
+
+  python bench.py [--gpus N --steps K --warmup W]          (N>1: launched by
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md section "Measurement").
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CFG = dict(B=64, T=128, J=67, nW=5, C=2, d0=128, nc=2002)
+HBM_PEAK = 8.0e12           # B/s, MI355X_MICROARCH.md
+F32_MFMA_PEAK = 157.3e12    # FLOP/s
+
+
+def attn_bytes(E, itemsize, bwd):
+    """algorithmic bytes of one fused window-attention launch:
+    fwd reads q,k,v + writes o = 4E; bwd reads q,k,v,dO + writes dq,dk,dv = 7E
+    (delta is recomputed in-kernel, so o is not re-read: 7E, not 8E)."""
+    return (7 if bwd else 4) * E * itemsize
+
+
+def cpu_baseline(sample_b=2, steps=2):
+    """oracle (CPU restatement proven equal to the reference) timed on the host cores:
+    eval-mode fwd+bwd (the FASTEST reference variant) on a bounded
+    sample of the same workload shape."""
+    from oracle import hwgat_oracle as O
+    c = CFG
+    torch.manual_seed(1001)
+    cfg = dict(kp_dim=c["C"], temporal_dim=c["T"], num_classes=c["nc"], embed_dim=c["d0"], num_kps=c["nW"] * 16)
+    params = {k: v.requires_grad_(k not in ("B", "pos_encoder.pe"))
+              for k, v in O.synth_params(1, weight_std=0.02, **cfg).items()}
+    model = O.OracleHWGAT(params, num_kps=cfg["num_kps"], temporal_dim=c["T"])
+    g = torch.Generator().manual_seed(7)
+    x = torch.rand(sample_b, c["T"], c["nW"] * 16, c["C"], generator=g)
+    y = torch.randint(0, c["nc"], (sample_b,), generator=g)
+    best, best_threads = None, None
+    ncpu = os.cpu_count() or 1
+    for threads in sorted({min(16, ncpu), min(64, ncpu)}):       # keep the fairer (faster) thread count
+        torch.set_num_threads(threads)
+        times = []
+        for i in range(steps + 1):
+            for p in params.values():
+                p.grad = None
+            t0 = time.perf_counter()
+            O.smoothed_cross_entropy(model.forward(x), y).backward()
+            times.append(time.perf_counter() - t0)
+        if best is None or min(times[1:]) < best:
+            best, best_threads = min(times[1:]), threads
+    return {"value": round(sample_b / best, 3), "unit": "clips/s", "cores": best_threads,
+            "kind": "port",
+            "sample": f"oracle (torch CPU restatement) eval-mode fwd+bwd, B={sample_b} clips of the same "
+                      f"T={c['T']} K={c['nW'] * 16} C={c['C']} d0={c['d0']} shape, best of {steps} after 1 warm-up"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
+    ap.add_argument("--batch", type=int, default=CFG["B"], help="clips per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eval-mode", action="store_true", help="deterministic fwd+bwd (no dropout / attention drop)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if args.gpus > 1 and world == 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    hw = importlib.import_module("sl-hwgat_amd")
+    from importlib import import_module
+    train_mod = import_module("sl-hwgat_amd.train")
+    dist_mod = import_module("sl-hwgat_amd.dist")
+    HF = hw.functional
+
+    c = dict(CFG, B=args.batch)
+    torch.manual_seed(1001)                                       # reference configs.py:55-59
+    hp = hw.HWGATEParams({"src_len": c["T"], "num_class": c["nc"]}, c["C"], dev, num_kps=c["nW"] * 16,
+                         embed_dim=c["d0"])
+    model = hw.Model(*hp.get_model_params()).to(dev)
+    model.use_part_table(hw.part_table(c["J"], c["nW"]))
+    if args.dtype == "bf16":
+        model.set_activation_dtype(torch.bfloat16)
+    model.train(not args.eval_mode)
+    dist_mod.broadcast_parameters(model)
+    reducer = dist_mod.GradReducer(model.parameters()) if world > 1 else None
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=5e-4, fused=True)
+    step = train_mod.TrainStep(model, opt, reducer)
+
+    g = torch.Generator(device=dev).manual_seed(7 + rank)
+    x = torch.rand(c["B"], c["T"], c["J"], c["C"], device=dev, generator=g)
+    y = torch.randint(0, c["nc"], (c["B"],), device=dev, generator=g)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(x, y)
+    barrier()
+    HF.TIMERS = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(x, y)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    timers = HF.timers_summary()
+    HF.TIMERS = None
+    loss = float(step.loss)
+
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t)
+
+    if rank == 0:
+        itemsize = 4 if args.dtype == "f32" else 2
+        E = c["B"] * c["T"] * c["nW"] * 16 * c["d0"]
+        kern = {}
+        for name, bwd in (("hwgat_win_attn_fwd", False), ("hwgat_win_attn_bwd", True)):
+            n, ms = timers.get(name, (0, 0.0))
+            if n:
+                avg = ms / n * 1e-3
+                ach = attn_bytes(E, itemsize, bwd) / avg
+                kern[name] = {"bound": "hbm", "achieved": round(ach / 1e9, 1), "peak": HBM_PEAK / 1e9,
+                              "unit": "GB/s", "frac": round(ach / HBM_PEAK, 4), "traffic": None,
+                              "launches": n, "avg_us": round(avg * 1e6, 1),
+                              "bytes_per_launch": attn_bytes(E, itemsize, bwd)}
+        others = {k: {"launches": v[0], "total_ms": round(v[1], 3)} for k, v in timers.items()
+                  if k not in kern}
+        hip_ms = sum(v[1] for v in timers.values())
+        roof = dict(kern.get("hwgat_win_attn_bwd", {"bound": "hbm", "achieved": None, "peak": HBM_PEAK / 1e9,
+                                                    "unit": "GB/s", "frac": None, "traffic": None}))
+        roof["kernel"] = "win_attn_bwd_k (fused window graph-attention backward)"
+        out = {
+            "metric": "clips/sec fwd+bwd at B=64 T=128 J=67; %HBM roofline; 1->8 GPU scaling",
+            "value": round(world * c["B"] * args.steps / elapsed, 2), "unit": "clips/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: HWGAT train step (fwd+loss+bwd+AdamW), "
+                                   f"B={c['B']}/GPU T={c['T']} J={c['J']}->K={c['nW'] * 16} C={c['C']} "
+                                   f"d_model={c['d0']} depths[2,2,4] classes={c['nc']}, "
+                                   + ("eval-mode" if args.eval_mode else "train-mode drop 0.1"),
+                       "global_batch": world * c["B"], "parallelism": f"dp{world}"},
+            "roofline": roof,
+            "kernels": kern, "other_hip_entry_points": others,
+            "hip_kernel_ms_per_step": round(hip_ms / args.steps, 3),
+            "loss": round(loss, 4),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

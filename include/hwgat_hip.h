@@ -1,0 +1,114 @@
+/*
+ * hwgat_hip.h -- C ABI of libhwgat_hip.so, the MI355X (gfx950) backend for the
+ * HWGAT hot path (reference: hwgat/models/HWGATE.py).
+ *
+ * The reference has no native interface of its own (it is 100 % Python on
+ * ATen), so every entry point below cites the reference *Python* lines whose
+ * arithmetic it replaces.  Conventions for all entry points:
+ *
+ *   - plain device pointers + sizes, no torch types; the caller owns every
+ *     buffer, nothing is allocated or freed here; no global mutable state;
+ *   - `dtype` selects activation storage: HWGAT_F32 (0) or HWGAT_BF16 (1);
+ *     parameters, statistics and all arithmetic are fp32;
+ *   - `stream` is a hipStream_t passed as void*; launches are asynchronous and
+ *     stream-ordered; entry points are re-entrant;
+ *   - return 0 on success, a negative HWGAT_E* code on bad arguments (nothing
+ *     is launched then), or a positive hipError_t if the launch failed.
+ *
+ * Activations are kept in the natural token order (B, F, K, d) everywhere:
+ * window partition / reverse / cyclic roll (HWGATE.py:30-47,197-215) are pure
+ * index arithmetic inside the kernels and never materialised.
+ */
+#ifndef HWGAT_HIP_H
+#define HWGAT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HWGAT_F32 0
+#define HWGAT_BF16 1
+
+#define HWGAT_EINVAL (-1)   /* null pointer / non-positive size            */
+#define HWGAT_ESHAPE (-2)   /* unsupported shape (head_dim, width, ...)    */
+#define HWGAT_EDTYPE (-3)   /* unknown dtype code                          */
+
+/* library / ABI version: major*1000 + minor */
+int hwgat_abi_version(void);
+
+/* ---- debug: dump the lane->element maps of v_mfma_f32_32x32x2_f32 so the
+ * host can verify the operand layouts the kernels assume.  out: 64*16 floats
+ * = D tile of A(32x2) . B(2x32) with A[i][k] = a[i*2+k], B[k][j] = b[k*32+j]. */
+int hwgat_debug_mfma32x32x2(const float* a, const float* b, float* out, void* stream);
+
+/* ---- a-2/a-3/a-12: part gather + Fourier features + positional encoding.
+ * Replaces WindowCreate (dataTransform.py:445-455), the Fourier mapping
+ * (HWGATE.py:343-345) and PositionalEncoding's add (HWGATE.py:25-27).
+ *   x    (B, T, J, C) fp32 raw keypoints
+ *   idx  (K) int32 joint index per model slot, or NULL for identity (J == K)
+ *   bmat (d0/2, C) fp32 frozen Gaussian matrix (state_dict key "B")
+ *   pe   (T, d0) fp32 sinusoid table or NULL (pe=False)
+ *   out  (B, T, K, d0) `dtype`
+ *   out[..., m] = sin(p_m) + pe, out[..., d0/2+m] = cos(p_m) + pe,
+ *   p_m = sum_c (2*pi*x_c) * bmat[m][c]  (fp32, accurate range reduction). */
+int hwgat_embed_fwd(const float* x, const int32_t* idx, const float* bmat, const float* pe,
+                    void* out, int B, int T, int J, int K, int C, int d0, int dtype,
+                    void* stream);
+
+/* ---- LayerNorm over the last axis (HWGATE.py:203, 219, 353), eps 1e-5.
+ *   x, y (N, d) `dtype`; gamma, beta (d) fp32; mean, rstd (N) fp32 (saved
+ *   for backward).  d in {128, 256, 512, 1024}. */
+int hwgat_ln_fwd(const void* x, const float* gamma, const float* beta, void* y,
+                 float* mean, float* rstd, int64_t N, int d, int dtype, void* stream);
+
+/* backward of hwgat_ln_fwd.  dx = dLN/dx (+ dres if dres != NULL, the
+ * shortcut gradient of HWGATE.py:217/219); dgamma, dbeta (d) fp32 are
+ * ACCUMULATED into (caller zeroes them once per step). */
+int hwgat_ln_bwd(const void* dy, const void* x, const float* mean, const float* rstd,
+                 const float* gamma, const void* dres, void* dx, float* dgamma, float* dbeta,
+                 int64_t N, int d, int dtype, void* stream);
+
+/* ---- a-4/a-5/a-6/a-10: fused window attention (MSA.forward, HWGATE.py:89-114)
+ * over the body-part joint graph, with partition/roll/reverse as index math.
+ *   qkv      (B, F, K, 3, nH, hd) `dtype` -- the qkv Linear output in natural
+ *            token order (HWGATE.py:86 column order [q|k|v][head][hd])
+ *   o        (B, F, K, nH, hd) `dtype`   -- heads concatenated (HWGATE.py:114)
+ *   maskbits (2, nW, 32) uint32: bit j of word [s][w][i] = key j visible to
+ *            query i in part window w; s=0 adjacency only (HWGATE.py:106-108),
+ *            s=1 adjacency AND last-slot shift mask (HWGATE.py:102-104,169-187)
+ *   thr      device pointer to ONE fp32 probability threshold (train mode,
+ *            HWGATE.py:94-100) or NULL for eval mode
+ *   shifted  1 for odd blocks (roll by -1 frame before, +1 after; HWGATE.py:197-211)
+ * K = nW*16, F even, hd in {32, 64, 128}.  Semantics incl. the "== 0 -> -10000"
+ * fill and uniform all-masked rows are exactly SURVEY.md 8a "MSA exact semantics". */
+int hwgat_win_attn_fwd(const void* qkv, void* o, const uint32_t* maskbits, const float* thr,
+                       int B, int F, int nW, int nH, int hd, int shifted, int dtype,
+                       void* stream);
+
+/* backward: do (B,F,K,nH,hd) -> dqkv (B,F,K,3,nH,hd); probabilities are
+ * recomputed from qkv (+ the same thr), nothing is saved by the forward. */
+int hwgat_win_attn_bwd(const void* qkv, const void* dO, void* dqkv, const uint32_t* maskbits,
+                       const float* thr, int B, int F, int nW, int nH, int hd, int shifted,
+                       int dtype, void* stream);
+
+/* ---- a-11: final LayerNorm + mean over all f*K tokens (HWGATE.py:353-354).
+ *   x (B, n_tok, d) `dtype`; feat (B, d) fp32 must be ZERO on entry (sums of
+ *   normalised values are accumulated, then hwgat_lnpool_finish scales them);
+ *   mean, rstd (B*n_tok) fp32 saved. */
+int hwgat_lnpool_fwd(const void* x, float* xhat_sum, float* mean, float* rstd,
+                     int B, int n_tok, int d, int dtype, void* stream);
+/* backward: g (B, d) fp32 = dfeat * gamma / n_tok  ->  dx (B, n_tok, d) */
+int hwgat_lnpool_bwd(const float* g, const void* x, const float* mean, const float* rstd,
+                     void* dx, int B, int n_tok, int d, int dtype, void* stream);
+
+/* ---- a-9: TemporalMerging (HWGATE.py:55-63): (B,F,K,d) -> (B,F/2,K,2d),
+ * out[b,fi,k,tp*d+c] = in[b,2fi+tp,k,c]; `inverse` = 1 maps gradients back. */
+int hwgat_merge(const void* in, void* out, int B, int F, int K, int d, int inverse,
+                int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HWGAT_HIP_H */

@@ -1,0 +1,87 @@
+"""ctypes binding of libhwgat_hip.so (the C-ABI declared in include/hwgat_hip.h).
+
+There is deliberately NO fallback: if the HIP library is missing or a launcher
+returns an error, this raises.  torch is used only to obtain device pointers
+and the current HIP stream.
+"""
+import ctypes
+import os
+import re
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhwgat_hip.so")
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "hwgat_hip.h")
+
+F32, BF16 = 0, 1
+_ERR = {-1: "HWGAT_EINVAL (null pointer / bad size)", -2: "HWGAT_ESHAPE (unsupported shape)",
+        -3: "HWGAT_EDTYPE (unknown dtype)"}
+
+_P, _I, _L = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+_SIGS = {
+    "hwgat_abi_version": [],
+    "hwgat_debug_mfma32x32x2": [_P, _P, _P, _P],
+    "hwgat_embed_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "hwgat_ln_fwd": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
+    "hwgat_ln_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
+    "hwgat_win_attn_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "hwgat_win_attn_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "hwgat_lnpool_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "hwgat_lnpool_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "hwgat_merge": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
+}
+_lib = None
+
+
+def declared_symbols():
+    """every function name declared in include/hwgat_hip.h"""
+    with open(HEADER) as fh:
+        src = re.sub(r"/\*.*?\*/", "", fh.read(), flags=re.S)
+    return sorted(set(re.findall(r"\bint\s+(hwgat_\w+)\s*\(", src)))
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HWGAT HIP backend is not built. Run "
+                "`python sl-hwgat_amd/build.py` (hipcc --offload-arch=gfx950). "
+                "There is no CPU fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, args in _SIGS.items():
+            fn = getattr(handle, name)
+            fn.argtypes = args
+            fn.restype = _I
+        _lib = handle
+    return _lib
+
+
+def dtype_code(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported activation dtype {t.dtype}")
+
+
+def ptr(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("HWGAT HIP kernels need tensors on an MI355X device (got a CPU tensor); "
+                           "there is no CPU fallback")
+    if not t.is_contiguous():
+        raise ValueError("HWGAT HIP kernels need contiguous tensors")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    rc = getattr(lib(), name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed: {_ERR.get(rc, 'hipError ' + str(rc))}")

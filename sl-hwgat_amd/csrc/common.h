@@ -1,0 +1,62 @@
+// Shared device helpers for the HWGAT gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/hwgat_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+#define HWGAT_WAVE 64
+
+#define HWGAT_LAUNCH_CHECK()                          \
+    do {                                              \
+        hipError_t e__ = hipGetLastError();           \
+        return e__ == hipSuccess ? 0 : (int)e__;      \
+    } while (0)
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// row index of accumulator register r of v_mfma_f32_32x32x2_f32 for lane half h
+__device__ __forceinline__ constexpr int crow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+template <typename T> struct io;
+template <> struct io<float> {
+    static constexpr int EPV = 4;                       // elements per 16-byte vector
+    __device__ static __forceinline__ void load4(const float* p, float (&v)[4]) {
+        f32x4 t = *reinterpret_cast<const f32x4*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+    __device__ static __forceinline__ void store4(float* p, const float (&v)[4]) {
+        f32x4 t = {v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(p) = t;
+    }
+    __device__ static __forceinline__ float ld(const float* p) { return *p; }
+    __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct io<bf16_t> {
+    static constexpr int EPV = 8;
+    __device__ static __forceinline__ void load4(const bf16_t* p, float (&v)[4]) {
+        bf16x4 t = *reinterpret_cast<const bf16x4*>(p);
+        v[0] = (float)t.x; v[1] = (float)t.y; v[2] = (float)t.z; v[3] = (float)t.w;
+    }
+    __device__ static __forceinline__ void store4(bf16_t* p, const float (&v)[4]) {
+        bf16x4 t = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+        *reinterpret_cast<bf16x4*>(p) = t;
+    }
+    __device__ static __forceinline__ float ld(const bf16_t* p) { return (float)*p; }
+    __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = (bf16_t)v; }
+};
+
+// butterfly all-reduce over the low `W` lanes-groups (W = 32 or 64)
+template <int W>
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}

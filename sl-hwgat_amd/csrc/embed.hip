@@ -1,0 +1,105 @@
+// Part gather + Fourier feature mapping + positional encoding, and TemporalMerging,
+// for HWGAT on gfx950.
+//
+// embed: replaces WindowCreate's host-side numpy gather (reference
+// hwgat/dataTransform.py:445-455), the Fourier mapping (hwgat/models/HWGATE.py:343-345)
+// and PositionalEncoding's add (HWGATE.py:25-27) with one streaming kernel: each
+// lane computes one projection p_m, one sincosf, and writes the sin half and the cos
+// half of the token row (two fully coalesced row segments per wave).  Arguments reach
+// hundreds of radians, so the accurate (range-reducing) sincosf is used on purpose.
+//
+// merge: TemporalMerging (HWGATE.py:55-63) as a 16-byte-vector permutation copy.
+#include "common.h"
+
+namespace {
+
+template <typename T, int C>
+__global__ __launch_bounds__(256) void embed_fwd_k(const float* __restrict__ x, const int32_t* __restrict__ idx,
+                                                   const float* __restrict__ bmat, const float* __restrict__ pe,
+                                                   T* __restrict__ out, int64_t n_tok, int T_, int J, int K,
+                                                   int d0) {
+    const int half = d0 >> 1;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwave = (int64_t)gridDim.x * 4;
+    constexpr float TWO_PI = 6.283185307179586f;            // float(2.*torch.pi), HWGATE.py:343
+    for (int m0 = 0; m0 < half; m0 += 64) {
+        const int m = m0 + lane;
+        const bool act = m < half;
+        float bw[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) bw[c] = act ? bmat[m * C + c] : 0.f;
+        for (int64_t tok = wave; tok < n_tok; tok += nwave) {
+            const int k = (int)(tok % K);
+            const int64_t bt = tok / K;
+            const int t = (int)(bt % T_);
+            const int j = idx ? idx[k] : k;
+            const float* xp = x + (bt * J + j) * C;
+            float p = (TWO_PI * xp[0]) * bw[0];
+#pragma unroll
+            for (int c = 1; c < C; ++c) p = fmaf(TWO_PI * xp[c], bw[c], p);
+            float sn, cs;
+            sincosf(p, &sn, &cs);
+            if (pe) { sn += pe[t * d0 + m]; cs += pe[t * d0 + half + m]; }
+            if (act) {
+                io<T>::st(out + tok * d0 + m, sn);
+                io<T>::st(out + tok * d0 + half + m, cs);
+            }
+        }
+    }
+}
+
+// 16-byte chunks; forward: out[b,fi,k,tp*d+c] = in[b,2fi+tp,k,c]
+template <typename T>
+__global__ __launch_bounds__(256) void merge_k(const T* __restrict__ in, T* __restrict__ out, int64_t n_chunks,
+                                               int F, int K, int d, int inverse) {
+    constexpr int EPV = io<T>::EPV;
+    const int cpr = d / EPV;                                   // chunks per input row
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_chunks; i += (int64_t)gridDim.x * 256) {
+        // i indexes the un-merged tensor (b, F, K, cpr)
+        const int c = (int)(i % cpr);
+        int64_t r = i / cpr;
+        const int k = (int)(r % K); r /= K;
+        const int fr = (int)(r % F);
+        const int64_t b = r / F;
+        const int64_t j = (((b * (F / 2) + (fr >> 1)) * K + k) * 2 + (fr & 1)) * cpr + c;
+        const u32x4* src = reinterpret_cast<const u32x4*>(in);
+        u32x4* dst = reinterpret_cast<u32x4*>(out);
+        if (inverse) dst[i] = src[j]; else dst[j] = src[i];
+    }
+}
+
+}  // namespace
+
+extern "C" int hwgat_embed_fwd(const float* x, const int32_t* idx, const float* bmat, const float* pe, void* out,
+                               int B, int T, int J, int K, int C, int d0, int dtype, void* stream) {
+    if (!x || !bmat || !out || B <= 0 || T <= 0 || J <= 0 || K <= 0) return HWGAT_EINVAL;
+    if (d0 <= 0 || (d0 & 1) || (!idx && J != K) || (C != 2 && C != 3)) return HWGAT_ESHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n_tok = (int64_t)B * T * K;
+    const int grid = (int)(n_tok / 4 < 2048 ? (n_tok + 3) / 4 : 2048);
+#define GO(TT, CC) embed_fwd_k<TT, CC><<<grid, 256, 0, st>>>(x, idx, bmat, pe, (TT*)out, n_tok, T, J, K, d0)
+    if (dtype == HWGAT_F32) { if (C == 2) GO(float, 2); else GO(float, 3); }
+    else if (dtype == HWGAT_BF16) { if (C == 2) GO(bf16_t, 2); else GO(bf16_t, 3); }
+    else return HWGAT_EDTYPE;
+#undef GO
+    HWGAT_LAUNCH_CHECK();
+}
+
+extern "C" int hwgat_merge(const void* in, void* out, int B, int F, int K, int d, int inverse, int dtype,
+                           void* stream) {
+    if (!in || !out || B <= 0 || F <= 0 || K <= 0 || d <= 0) return HWGAT_EINVAL;
+    if (F & 1) return HWGAT_ESHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype != HWGAT_F32 && dtype != HWGAT_BF16) return HWGAT_EDTYPE;
+    const int epv = dtype == HWGAT_F32 ? 4 : 8;
+    if (d % epv) return HWGAT_ESHAPE;
+    const int64_t n = (int64_t)B * F * K * (d / epv);
+    const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    if (dtype == HWGAT_F32) merge_k<float><<<grid, 256, 0, st>>>((const float*)in, (float*)out, n, F, K, d, inverse);
+    else merge_k<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)in, (bf16_t*)out, n, F, K, d, inverse);
+    HWGAT_LAUNCH_CHECK();
+}
+
+extern "C" int hwgat_abi_version(void) { return 1000; }

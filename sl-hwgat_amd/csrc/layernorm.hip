@@ -1,0 +1,357 @@
+// LayerNorm forward/backward and the fused final LayerNorm + token mean-pool for
+// HWGAT on gfx950.  Reference: nn.LayerNorm at hwgat/models/HWGATE.py:162,166
+// (per block, applied at :203 and :219) and :327 (final, applied at :353) with
+// the AvgPool1d over all f*K tokens at :354.
+//
+// All of these are pure HBM-streaming kernels: a row of d in {128..1024} values
+// is owned by LPR = min(64, d/4) lanes, each lane holding d/(4*LPR) 16-byte
+// chunks, so every global access is a full 16 B/lane coalesced vector; statistics
+// are two-pass in registers (mean, then centred variance) in fp32.
+#include "common.h"
+
+namespace {
+
+constexpr float LN_EPS = 1e-5f;
+
+template <int D> struct RowMap {
+    static constexpr int NCH = D / 4;                         // 4-element chunks per row
+    static constexpr int LPR = NCH < 64 ? NCH : 64;           // lanes per row
+    static constexpr int RPW = 64 / LPR;                      // rows per wave pass
+    static constexpr int CPL = NCH / LPR;                     // chunks per lane
+};
+
+template <typename T, int D>
+__device__ __forceinline__ void load_row(const T* row, int sub, float (&v)[RowMap<D>::CPL][4]) {
+#pragma unroll
+    for (int c = 0; c < RowMap<D>::CPL; ++c) io<T>::load4(row + (c * RowMap<D>::LPR + sub) * 4, v[c]);
+}
+template <typename T, int D>
+__device__ __forceinline__ void store_row(T* row, int sub, const float (&v)[RowMap<D>::CPL][4]) {
+#pragma unroll
+    for (int c = 0; c < RowMap<D>::CPL; ++c) io<T>::store4(row + (c * RowMap<D>::LPR + sub) * 4, v[c]);
+}
+template <int D>
+__device__ __forceinline__ void load_vec(const float* p, int sub, float (&v)[RowMap<D>::CPL][4]) {
+#pragma unroll
+    for (int c = 0; c < RowMap<D>::CPL; ++c) io<float>::load4(p + (c * RowMap<D>::LPR + sub) * 4, v[c]);
+}
+
+template <int D>
+__device__ __forceinline__ void row_stats(const float (&v)[RowMap<D>::CPL][4], float& mean, float& rstd) {
+    using M = RowMap<D>;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < M::CPL; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += v[c][e];
+    mean = wave_sum<M::LPR>(s) * (1.0f / D);
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < M::CPL; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float t = v[c][e] - mean; q += t * t; }
+    rstd = rsqrtf(wave_sum<M::LPR>(q) * (1.0f / D) + LN_EPS);
+}
+
+// ------------------------------------------------------------------ forward
+template <typename T, int D>
+__global__ __launch_bounds__(256) void ln_fwd_k(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                const float* __restrict__ beta, T* __restrict__ y,
+                                                float* __restrict__ mean_o, float* __restrict__ rstd_o,
+                                                int64_t N) {
+    using M = RowMap<D>;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % M::LPR, rsub = lane / M::LPR;
+    float g[M::CPL][4], b[M::CPL][4];
+    load_vec<D>(gamma, sub, g);
+    load_vec<D>(beta, sub, b);
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nwave = (int64_t)gridDim.x * 4;
+    for (int64_t r0 = wave * M::RPW; r0 < N; r0 += nwave * M::RPW) {
+        const int64_t r = r0 + rsub;
+        if (r >= N) continue;                      // only when N % RPW != 0 (whole row group idle)
+        float v[M::CPL][4];
+        load_row<T, D>(x + r * D, sub, v);
+        float mean, rstd;
+        row_stats<D>(v, mean, rstd);
+#pragma unroll
+        for (int c = 0; c < M::CPL; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[c][e] = (v[c][e] - mean) * rstd * g[c][e] + b[c][e];
+        store_row<T, D>(y + r * D, sub, v);
+        if (sub == 0) { mean_o[r] = mean; rstd_o[r] = rstd; }
+    }
+}
+
+// ------------------------------------------------------------------ backward
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma
+template <typename T, int D, bool RES>
+__global__ __launch_bounds__(256) void ln_bwd_k(const T* __restrict__ dy, const T* __restrict__ x,
+                                                const float* __restrict__ mean_i,
+                                                const float* __restrict__ rstd_i,
+                                                const float* __restrict__ gamma, const T* __restrict__ dres,
+                                                T* __restrict__ dx, float* __restrict__ dgamma,
+                                                float* __restrict__ dbeta, int64_t N) {
+    using M = RowMap<D>;
+    __shared__ float red[2][4][D];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int sub = lane % M::LPR, rsub = lane / M::LPR;
+    float g[M::CPL][4], dg[M::CPL][4], db[M::CPL][4];
+    load_vec<D>(gamma, sub, g);
+#pragma unroll
+    for (int c = 0; c < M::CPL; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { dg[c][e] = 0.f; db[c][e] = 0.f; }
+    const int64_t wave = (int64_t)blockIdx.x * 4 + wv;
+    const int64_t nwave = (int64_t)gridDim.x * 4;
+    for (int64_t r0 = wave * M::RPW; r0 < N; r0 += nwave * M::RPW) {
+        const int64_t r = r0 + rsub;
+        if (r >= N) continue;
+        float xv[M::CPL][4], dv[M::CPL][4];
+        load_row<T, D>(x + r * D, sub, xv);
+        load_row<T, D>(dy + r * D, sub, dv);
+        const float mean = mean_i[r], rstd = rstd_i[r];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < M::CPL; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xh = (xv[c][e] - mean) * rstd;
+                const float gg = dv[c][e] * g[c][e];
+                dg[c][e] += dv[c][e] * xh;
+                db[c][e] += dv[c][e];
+                xv[c][e] = xh;
+                dv[c][e] = gg;
+                s1 += gg;
+                s2 += gg * xh;
+            }
+        s1 = wave_sum<M::LPR>(s1) * (1.0f / D);
+        s2 = wave_sum<M::LPR>(s2) * (1.0f / D);
+        if constexpr (RES) {
+            float rv[M::CPL][4];
+            load_row<T, D>(dres + r * D, sub, rv);
+#pragma unroll
+            for (int c = 0; c < M::CPL; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dv[c][e] = rstd * (dv[c][e] - s1 - xv[c][e] * s2) + rv[c][e];
+        } else {
+#pragma unroll
+            for (int c = 0; c < M::CPL; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dv[c][e] = rstd * (dv[c][e] - s1 - xv[c][e] * s2);
+        }
+        store_row<T, D>(dx + r * D, sub, dv);
+    }
+    // fold the RPW row groups of a wave, then the 4 waves, then one atomic per column per block
+    if constexpr (M::RPW == 2) {
+#pragma unroll
+        for (int c = 0; c < M::CPL; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                dg[c][e] += __shfl_xor(dg[c][e], 32, 64);
+                db[c][e] += __shfl_xor(db[c][e], 32, 64);
+            }
+    }
+    if (rsub == 0) {
+#pragma unroll
+        for (int c = 0; c < M::CPL; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                red[0][wv][(c * M::LPR + sub) * 4 + e] = dg[c][e];
+                red[1][wv][(c * M::LPR + sub) * 4 + e] = db[c][e];
+            }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < D; i += 256) {
+        atomicAdd(dgamma + i, red[0][0][i] + red[0][1][i] + red[0][2][i] + red[0][3][i]);
+        atomicAdd(dbeta + i, red[1][0][i] + red[1][1][i] + red[1][2][i] + red[1][3][i]);
+    }
+}
+
+// ------------------------------------------------------------------ LN + pool
+// xhat_sum[b][c] += sum over this wave's tokens of (x - mean) * rstd
+template <typename T, int D>
+__global__ __launch_bounds__(256) void lnpool_fwd_k(const T* __restrict__ x, float* __restrict__ xhat_sum,
+                                                    float* __restrict__ mean_o, float* __restrict__ rstd_o,
+                                                    int n_tok, int chunks) {
+    using M = RowMap<D>;
+    __shared__ float red[4][D];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int sub = lane % M::LPR, rsub = lane / M::LPR;
+    const int b = blockIdx.x / chunks, ch = blockIdx.x % chunks;
+    const int per = (n_tok + chunks - 1) / chunks;
+    const int t0 = ch * per, t1 = min(n_tok, t0 + per);
+    float acc[M::CPL][4];
+#pragma unroll
+    for (int c = 0; c < M::CPL; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[c][e] = 0.f;
+    for (int t = t0 + wv * M::RPW + rsub; t < t1; t += 4 * M::RPW) {
+        const int64_t r = (int64_t)b * n_tok + t;
+        float v[M::CPL][4];
+        load_row<T, D>(x + r * D, sub, v);
+        float mean, rstd;
+        row_stats<D>(v, mean, rstd);
+#pragma unroll
+        for (int c = 0; c < M::CPL; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[c][e] += (v[c][e] - mean) * rstd;
+        if (sub == 0) { mean_o[r] = mean; rstd_o[r] = rstd; }
+    }
+    if constexpr (M::RPW == 2) {
+#pragma unroll
+        for (int c = 0; c < M::CPL; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[c][e] += __shfl_xor(acc[c][e], 32, 64);
+    }
+    if (rsub == 0) {
+#pragma unroll
+        for (int c = 0; c < M::CPL; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[wv][(c * M::LPR + sub) * 4 + e] = acc[c][e];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < D; i += 256)
+        atomicAdd(xhat_sum + (int64_t)b * D + i, red[0][i] + red[1][i] + red[2][i] + red[3][i]);
+}
+
+// the upstream gradient of every token of clip b is the same vector g[b] (fp32)
+template <typename T, int D>
+__global__ __launch_bounds__(256) void lnpool_bwd_k(const float* __restrict__ g, const T* __restrict__ x,
+                                                    const float* __restrict__ mean_i,
+                                                    const float* __restrict__ rstd_i, T* __restrict__ dx,
+                                                    int n_tok, int chunks) {
+    using M = RowMap<D>;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int sub = lane % M::LPR, rsub = lane / M::LPR;
+    const int b = blockIdx.x / chunks, ch = blockIdx.x % chunks;
+    const int per = (n_tok + chunks - 1) / chunks;
+    const int t0 = ch * per, t1 = min(n_tok, t0 + per);
+    float gv[M::CPL][4];
+    load_vec<D>(g + (int64_t)b * D, sub, gv);
+    float s1 = 0.f;
+#pragma unroll
+    for (int c = 0; c < M::CPL; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s1 += gv[c][e];
+    s1 = wave_sum<M::LPR>(s1) * (1.0f / D);
+    for (int t = t0 + wv * M::RPW + rsub; t < t1; t += 4 * M::RPW) {
+        const int64_t r = (int64_t)b * n_tok + t;
+        float v[M::CPL][4];
+        load_row<T, D>(x + r * D, sub, v);
+        const float mean = mean_i[r], rstd = rstd_i[r];
+        float s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < M::CPL; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[c][e] = (v[c][e] - mean) * rstd; s2 += gv[c][e] * v[c][e]; }
+        s2 = wave_sum<M::LPR>(s2) * (1.0f / D);
+#pragma unroll
+        for (int c = 0; c < M::CPL; ++c)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[c][e] = rstd * (gv[c][e] - s1 - v[c][e] * s2);
+        store_row<T, D>(dx + r * D, sub, v);
+    }
+}
+
+inline int ln_grid(int64_t N, int rpw) {
+    const int64_t need = (N + 4 * rpw - 1) / (4 * rpw);
+    return (int)(need < 2048 ? (need < 1 ? 1 : need) : 2048);
+}
+
+template <typename T>
+int ln_fwd_t(const void* x, const float* gm, const float* bt, void* y, float* mean, float* rstd, int64_t N,
+             int d, hipStream_t st) {
+#define GO(D) ln_fwd_k<T, D><<<ln_grid(N, RowMap<D>::RPW), 256, 0, st>>>((const T*)x, gm, bt, (T*)y, mean, rstd, N)
+    switch (d) {
+        case 128: GO(128); break;
+        case 256: GO(256); break;
+        case 512: GO(512); break;
+        case 1024: GO(1024); break;
+        default: return HWGAT_ESHAPE;
+    }
+#undef GO
+    HWGAT_LAUNCH_CHECK();
+}
+template <typename T, bool RES>
+int ln_bwd_t(const void* dy, const void* x, const float* mean, const float* rstd, const float* gm,
+             const void* dres, void* dx, float* dg, float* db, int64_t N, int d, hipStream_t st) {
+#define GO(D)                                                                                              \
+    ln_bwd_k<T, D, RES><<<(ln_grid(N, RowMap<D>::RPW) < 1024 ? ln_grid(N, RowMap<D>::RPW) : 1024), 256, 0, \
+                          st>>>((const T*)dy, (const T*)x, mean, rstd, gm, (const T*)dres, (T*)dx, dg, db, N)
+    switch (d) {
+        case 128: GO(128); break;
+        case 256: GO(256); break;
+        case 512: GO(512); break;
+        case 1024: GO(1024); break;
+        default: return HWGAT_ESHAPE;
+    }
+#undef GO
+    HWGAT_LAUNCH_CHECK();
+}
+inline int pool_chunks(int B, int n_tok) {
+    int c = 2048 / (B > 0 ? B : 1);
+    if (c < 1) c = 1;
+    const int maxc = (n_tok + 7) / 8;
+    return c < maxc ? c : (maxc < 1 ? 1 : maxc);
+}
+
+}  // namespace
+
+extern "C" int hwgat_ln_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                            float* rstd, int64_t N, int d, int dtype, void* stream) {
+    if (!x || !gamma || !beta || !y || !mean || !rstd || N <= 0) return HWGAT_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == HWGAT_F32) return ln_fwd_t<float>(x, gamma, beta, y, mean, rstd, N, d, st);
+    if (dtype == HWGAT_BF16) return ln_fwd_t<bf16_t>(x, gamma, beta, y, mean, rstd, N, d, st);
+    return HWGAT_EDTYPE;
+}
+
+extern "C" int hwgat_ln_bwd(const void* dy, const void* x, const float* mean, const float* rstd,
+                            const float* gamma, const void* dres, void* dx, float* dgamma, float* dbeta,
+                            int64_t N, int d, int dtype, void* stream) {
+    if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || N <= 0) return HWGAT_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == HWGAT_F32)
+        return dres ? ln_bwd_t<float, true>(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, N, d, st)
+                    : ln_bwd_t<float, false>(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, N, d, st);
+    if (dtype == HWGAT_BF16)
+        return dres ? ln_bwd_t<bf16_t, true>(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, N, d, st)
+                    : ln_bwd_t<bf16_t, false>(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, N, d, st);
+    return HWGAT_EDTYPE;
+}
+
+extern "C" int hwgat_lnpool_fwd(const void* x, float* xhat_sum, float* mean, float* rstd, int B, int n_tok,
+                                int d, int dtype, void* stream) {
+    if (!x || !xhat_sum || !mean || !rstd || B <= 0 || n_tok <= 0) return HWGAT_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int ch = pool_chunks(B, n_tok);
+#define GO(T, D) lnpool_fwd_k<T, D><<<B * ch, 256, 0, st>>>((const T*)x, xhat_sum, mean, rstd, n_tok, ch)
+#define SW(T)                                  \
+    switch (d) {                               \
+        case 128: GO(T, 128); break;           \
+        case 256: GO(T, 256); break;           \
+        case 512: GO(T, 512); break;           \
+        case 1024: GO(T, 1024); break;         \
+        default: return HWGAT_ESHAPE;          \
+    }
+    if (dtype == HWGAT_F32) { SW(float) }
+    else if (dtype == HWGAT_BF16) { SW(bf16_t) }
+    else return HWGAT_EDTYPE;
+#undef GO
+    HWGAT_LAUNCH_CHECK();
+}
+
+extern "C" int hwgat_lnpool_bwd(const float* g, const void* x, const float* mean, const float* rstd, void* dx,
+                                int B, int n_tok, int d, int dtype, void* stream) {
+    if (!g || !x || !mean || !rstd || !dx || B <= 0 || n_tok <= 0) return HWGAT_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int ch = pool_chunks(B, n_tok);
+#define GO(T, D) lnpool_bwd_k<T, D><<<B * ch, 256, 0, st>>>(g, (const T*)x, mean, rstd, (T*)dx, n_tok, ch)
+    if (dtype == HWGAT_F32) { SW(float) }
+    else if (dtype == HWGAT_BF16) { SW(bf16_t) }
+    else return HWGAT_EDTYPE;
+#undef GO
+#undef SW
+    HWGAT_LAUNCH_CHECK();
+}

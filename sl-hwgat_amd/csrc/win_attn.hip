@@ -1,0 +1,506 @@
+// Fused window graph-attention for HWGAT on gfx950 (MI355X).
+//
+// Replaces MSA.forward's attention core (reference hwgat/models/HWGATE.py:89-114)
+// together with window_partition / window_reverse / torch.roll
+// (HWGATE.py:30-47,197-215), which become index arithmetic here.
+//
+// Work unit = one (window, head): 32 tokens (2 frames x 16 joints of one body
+// part window) x head_dim.  One 64-lane wavefront owns a unit end to end, with a
+// wave-private LDS region, so the kernel has no workgroup barriers at all.
+//
+//   S^T = K Q^T            32 x v_mfma_f32_32x32x2_f32 (exact fp32 fma chains);
+//                          computed "swapped" so that a lane holds 16 keys of
+//                          ONE query row (partner lane^32 holds the other 16):
+//                          row max / row sum are 15 in-lane ops + 1 shuffle.
+//   masks + softmax        in registers (adjacency / shift bit rows, the train
+//                          mode probability-threshold drop, the "== 0 -> -10000"
+//                          fill, exactly as SURVEY.md 8a lists them)
+//   O = P V                P stays in the accumulator layout and is fed straight
+//                          back as the MFMA A operand (k-step r pairs keys
+//                          crow(r,0), crow(r,1)); V streams from HBM directly
+//                          into the B-operand layout, never touching LDS.
+//
+// HBM traffic is exactly the algorithmic 4*E*s (fwd) / 7*E*s (bwd): every q,k,v
+// (and dO) element is read once, every o (dq,dk,dv) element written once; all
+// rows are 128-byte-line aligned segments of hd*s bytes.
+#include "common.h"
+
+namespace {
+
+struct WinGeom {
+    int F, K, nW, nH, f, d, shift;
+};
+
+template <int HD> __device__ __forceinline__ constexpr float qk_scale() {
+    // float(head_dim ** -0.5), HWGATE.py:75,89
+    return HD == 16 ? 0.25f : HD == 32 ? 0.17677669529663687f : HD == 64 ? 0.125f : 0.08838834764831845f;
+}
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// 16-byte raw chunk -> floats written to LDS (optionally scaled)
+template <typename T> struct chunk;
+template <> struct chunk<float> {
+    __device__ static __forceinline__ void to_lds(float* dst, u32x4 raw, float s) {
+        f32x4 v = {__uint_as_float(raw.x) * s, __uint_as_float(raw.y) * s,
+                   __uint_as_float(raw.z) * s, __uint_as_float(raw.w) * s};
+        *reinterpret_cast<f32x4*>(dst) = v;
+    }
+};
+template <> struct chunk<bf16_t> {
+    __device__ static __forceinline__ void to_lds(float* dst, u32x4 raw, float s) {
+        f32x4 a = {__uint_as_float(raw.x << 16) * s, __uint_as_float(raw.x & 0xffff0000u) * s,
+                   __uint_as_float(raw.y << 16) * s, __uint_as_float(raw.y & 0xffff0000u) * s};
+        f32x4 b = {__uint_as_float(raw.z << 16) * s, __uint_as_float(raw.z & 0xffff0000u) * s,
+                   __uint_as_float(raw.w << 16) * s, __uint_as_float(raw.w & 0xffff0000u) * s};
+        reinterpret_cast<f32x4*>(dst)[0] = a;
+        reinterpret_cast<f32x4*>(dst)[1] = b;
+    }
+};
+
+// NT consecutive elements <-> floats (NT = 1, 2 or 4)
+template <typename T, int NT> __device__ __forceinline__ void load_nt(const T* p, float (&v)[NT]) {
+    if constexpr (sizeof(T) == 4) {
+        if constexpr (NT == 4) { f32x4 t = *reinterpret_cast<const f32x4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+        else if constexpr (NT == 2) { f32x2 t = *reinterpret_cast<const f32x2*>(p); v[0] = t.x; v[1] = t.y; }
+        else v[0] = *p;
+    } else {
+        if constexpr (NT == 4) { bf16x4 t = *reinterpret_cast<const bf16x4*>(p); v[0] = (float)t.x; v[1] = (float)t.y; v[2] = (float)t.z; v[3] = (float)t.w; }
+        else if constexpr (NT == 2) { bf16x2 t = *reinterpret_cast<const bf16x2*>(p); v[0] = (float)t.x; v[1] = (float)t.y; }
+        else v[0] = (float)*p;
+    }
+}
+template <typename T, int NT> __device__ __forceinline__ void store_nt(T* p, const float (&v)[NT]) {
+    if constexpr (sizeof(T) == 4) {
+        if constexpr (NT == 4) { f32x4 t = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<f32x4*>(p) = t; }
+        else if constexpr (NT == 2) { f32x2 t = {v[0], v[1]}; *reinterpret_cast<f32x2*>(p) = t; }
+        else *p = v[0];
+    } else {
+        if constexpr (NT == 4) { bf16x4 t = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]}; *reinterpret_cast<bf16x4*>(p) = t; }
+        else if constexpr (NT == 2) { bf16x2 t = {(bf16_t)v[0], (bf16_t)v[1]}; *reinterpret_cast<bf16x2*>(p) = t; }
+        else *p = (bf16_t)v[0];
+    }
+}
+
+// ---- unit decoding ---------------------------------------------------------
+struct Unit {
+    int64_t base0, base1;   // token index of slot 0 of frame A / frame B
+    int head, mrow;         // head index, row offset into maskbits
+};
+__device__ __forceinline__ Unit decode_unit(const WinGeom& g, int u) {
+    Unit r;
+    const int n = u / g.nH;
+    r.head = u - n * g.nH;
+    const int wi = n % g.nW;
+    const int t2 = n / g.nW;
+    const int fi = t2 % g.f;
+    const int b = t2 / g.f;
+    int fa = 2 * fi + g.shift, fb = fa + 1;          // torch.roll(x, -shift): shifted[t] = x[(t+shift) % F]
+    if (fa >= g.F) fa -= g.F;
+    if (fb >= g.F) fb -= g.F;
+    r.base0 = ((int64_t)b * g.F + fa) * g.K + wi * 16;
+    r.base1 = ((int64_t)b * g.F + fb) * g.K + wi * 16;
+    r.mrow = ((g.shift && fi == g.f - 1) ? g.nW : 0) * 32 + wi * 32;
+    return r;
+}
+__device__ __forceinline__ int64_t tok_of(const Unit& u, int t) {
+    return (t < 16 ? u.base0 : u.base1) + (t & 15);
+}
+
+// swap with the partner lane that holds the other 16 keys of the same query
+__device__ __forceinline__ float partner(float v) { return __shfl_xor(v, 32, 64); }
+
+// masks + softmax on one lane's 16 logits of query row (lane & 31).
+// s[r] = S[q][crow(r, hh)] on entry; p[r] = final probability on exit.
+// returns bit r set where the gradient flows (entry was not replaced by -10000).
+template <bool TRAIN>
+__device__ __forceinline__ uint32_t masked_softmax(float (&s)[16], float (&p)[16], uint32_t mrow_bits,
+                                                   int hh, float thr) {
+    if constexpr (TRAIN) {                                  // HWGATE.py:94-100
+        float m0 = s[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) m0 = fmaxf(m0, s[r]);
+        m0 = fmaxf(m0, partner(m0));
+        float e[16], sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { e[r] = expf(s[r] - m0); sum += e[r]; }
+        sum += partner(sum);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (e[r] / sum > thr) s[r] = 0.f;
+    }
+    uint32_t nz = 0;
+    float m = -3.0e38f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const bool vis = (mrow_bits >> crow(r, hh)) & 1u;   // HWGATE.py:102-108
+        float v = vis ? s[r] : 0.f;
+        if (v == 0.f) v = -10000.f; else nz |= 1u << r;     // HWGATE.py:110
+        s[r] = v;
+        m = fmaxf(m, v);
+    }
+    m = fmaxf(m, partner(m));
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { p[r] = expf(s[r] - m); sum += p[r]; }
+    sum += partner(sum);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) p[r] *= inv;               // HWGATE.py:111
+    return nz;
+}
+
+// D(32x32) += X Y^T for two row-per-lane LDS tiles X, Y of [32][LDW] floats.
+// result lane (j = lane&31, hh), reg r  ->  D[crow(r,hh)][j]  (rows index X).
+template <int HD, int LDW>
+__device__ __forceinline__ f32x16 tile_xyT(const float* X, const float* Y, int lq, int hh) {
+    f32x16 acc = {0.f};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const float* xr = X + lq * LDW + 4 * hh;
+    const float* yr = Y + lq * LDW + 4 * hh;
+#pragma unroll
+    for (int m = 0; m < HD / 8; ++m) {
+        const f32x4 xf = *reinterpret_cast<const f32x4*>(xr + 8 * m);
+        const f32x4 yf = *reinterpret_cast<const f32x4*>(yr + 8 * m);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xf.x, yf.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xf.y, yf.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xf.z, yf.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xf.w, yf.w, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+__device__ __forceinline__ void lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// =============================================================== forward
+template <typename T, int HD, bool TRAIN>
+__global__ __launch_bounds__(256, 2) void win_attn_fwd_k(const T* __restrict__ qkv, T* __restrict__ o,
+                                                         const uint32_t* __restrict__ maskbits,
+                                                         const float* __restrict__ thr_p, WinGeom g,
+                                                         int n_units) {
+    constexpr int LDW = HD + 4;
+    constexpr int NT = HD / 32;
+    constexpr int EPV = io<T>::EPV;
+    constexpr int CPR = HD / EPV;      // 16-byte chunks per row
+    constexpr int RPI = 64 / CPR;      // rows per wave-wide load
+    constexpr int NLD = 32 / RPI;      // wave-wide loads per tile
+    __shared__ __attribute__((aligned(16))) float smem[4 * 2 * 32 * LDW];
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lq = lane & 31, hh = lane >> 5;
+    float* Qs = smem + wave * (2 * 32 * LDW);
+    float* Ks = Qs + 32 * LDW;
+    const int crow_l = lane / CPR, ccol = (lane % CPR) * EPV;
+    const int64_t row3d = 3 * (int64_t)g.d;
+    const float thr = TRAIN ? *thr_p : 0.f;
+
+    const int nwaves = gridDim.x * 4;
+    int u = blockIdx.x * 4 + wave;
+    if (u >= n_units) return;
+
+    u32x4 qr[NLD], kr[NLD];
+    auto issue_qk = [&](const Unit& un) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const T* p = qkv + tok_of(un, i * RPI + crow_l) * row3d + un.head * HD + ccol;
+            qr[i] = *reinterpret_cast<const u32x4*>(p);
+            kr[i] = *reinterpret_cast<const u32x4*>(p + g.d);
+        }
+    };
+    Unit cur = decode_unit(g, u);
+    issue_qk(cur);
+
+    for (; u < n_units; u += nwaves) {
+        // -- stage Q (pre-scaled, HWGATE.py:89) and K into the wave's LDS tiles
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            float* dq = Qs + (i * RPI + crow_l) * LDW + ccol;
+            chunk<T>::to_lds(dq, qr[i], qk_scale<HD>());
+            chunk<T>::to_lds(dq + 32 * LDW, kr[i], 1.0f);
+        }
+        // -- V of this unit straight into the MFMA B-operand layout
+        float v[16][NT];
+        {
+            const T* vb = qkv + 2 * g.d + cur.head * HD + lq * NT;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) load_nt<T, NT>(vb + tok_of(cur, crow(r, hh)) * row3d, v[r]);
+        }
+        const uint32_t mbits = maskbits[cur.mrow + lq];
+        // -- prefetch next unit's q,k while this one computes
+        const int un = u + nwaves;
+        Unit nxt = cur;
+        if (un < n_units) { nxt = decode_unit(g, un); issue_qk(nxt); }
+        lds_fence();
+
+        f32x16 st = tile_xyT<HD, LDW>(Ks, Qs, lq, hh);     // st[r] = S[q=lq][key=crow(r,hh)]
+        float s[16], p[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = st[r];
+        masked_softmax<TRAIN>(s, p, mbits, hh, thr);
+
+        f32x16 oacc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) oacc[nt][i] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                oacc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(p[r], v[r][nt], oacc[nt], 0, 0, 0);
+
+        // lane (c=lq, hh), reg r -> O[q = crow(r,hh)][c*NT + nt]
+        T* ob = o + cur.head * HD + lq * NT;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float ov[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) ov[nt] = oacc[nt][r];
+            store_nt<T, NT>(ob + tok_of(cur, crow(r, hh)) * (int64_t)g.d, ov);
+        }
+        lds_fence();
+        cur = nxt;
+    }
+}
+
+// =============================================================== backward
+// acc(32 x HD) = A(32x32) . Y where the A operand value for k-step r is a[r]
+// (row = lane&31, k = crow(r,hh)) and Y is an LDS tile [32][LDW] read in the
+// B layout (lane (c,hh) reads Y[crow(r,hh)][c*NT .. +NT-1]).
+template <int HD, int LDW>
+__device__ __forceinline__ void tile_ay(const float (&a)[16], const float* Y, int lq, int hh,
+                                        f32x16 (&acc)[HD / 32]) {
+    constexpr int NT = HD / 32;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float y[NT];
+        const float* yp = Y + crow(r, hh) * LDW + lq * NT;
+        if constexpr (NT == 4) { f32x4 t = *reinterpret_cast<const f32x4*>(yp); y[0] = t.x; y[1] = t.y; y[2] = t.z; y[3] = t.w; }
+        else if constexpr (NT == 2) { f32x2 t = *reinterpret_cast<const f32x2*>(yp); y[0] = t.x; y[1] = t.y; }
+        else y[0] = *yp;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], y[nt], acc[nt], 0, 0, 0);
+    }
+}
+
+template <typename T, int HD, bool TRAIN, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 1) void win_attn_bwd_k(const T* __restrict__ qkv,
+                                                                const T* __restrict__ dO,
+                                                                T* __restrict__ dqkv,
+                                                                const uint32_t* __restrict__ maskbits,
+                                                                const float* __restrict__ thr_p,
+                                                                WinGeom g, int n_units) {
+    constexpr int LDW = HD + 4;
+    constexpr int NT = HD / 32;
+    constexpr int EPV = io<T>::EPV;
+    constexpr int CPR = HD / EPV;
+    constexpr int RPI = 64 / CPR;
+    constexpr int NLD = 32 / RPI;
+    constexpr int TW = 34;                                   // transpose scratch row stride
+    constexpr int SCR = 2 * 32 * TW;                         // P^T and dS^T scratch (floats)
+    constexpr int EXTRA = (32 * LDW >= SCR) ? 0 : SCR;       // scratch aliases the V tile when it fits
+    constexpr int PER_WAVE = 4 * 32 * LDW + EXTRA;
+    __shared__ __attribute__((aligned(16))) float smem[WAVES * PER_WAVE];
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lq = lane & 31, hh = lane >> 5;
+    float* Qs = smem + wave * PER_WAVE;
+    float* Ks = Qs + 32 * LDW;
+    float* Gs = Ks + 32 * LDW;
+    float* Vs = Gs + 32 * LDW;
+    float* Pt = EXTRA ? Vs + 32 * LDW : Vs;                   // [q][key], stride TW
+    float* Dt = Pt + 32 * TW;
+    const int crow_l = lane / CPR, ccol = (lane % CPR) * EPV;
+    const int64_t row3d = 3 * (int64_t)g.d;
+    const float thr = TRAIN ? *thr_p : 0.f;
+
+    const int nwaves = gridDim.x * WAVES;
+    int u = blockIdx.x * WAVES + wave;
+    if (u >= n_units) return;
+
+    u32x4 qr[NLD], kr[NLD], vr[NLD], gr[NLD];
+    auto issue = [&](const Unit& un) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int64_t tk = tok_of(un, i * RPI + crow_l);
+            const T* p = qkv + tk * row3d + un.head * HD + ccol;
+            qr[i] = *reinterpret_cast<const u32x4*>(p);
+            kr[i] = *reinterpret_cast<const u32x4*>(p + g.d);
+            vr[i] = *reinterpret_cast<const u32x4*>(p + 2 * g.d);
+            gr[i] = *reinterpret_cast<const u32x4*>(dO + tk * (int64_t)g.d + un.head * HD + ccol);
+        }
+    };
+    Unit cur = decode_unit(g, u);
+    issue(cur);
+
+    for (; u < n_units; u += nwaves) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int off = (i * RPI + crow_l) * LDW + ccol;
+            chunk<T>::to_lds(Qs + off, qr[i], qk_scale<HD>());
+            chunk<T>::to_lds(Ks + off, kr[i], 1.0f);
+            chunk<T>::to_lds(Vs + off, vr[i], 1.0f);
+            chunk<T>::to_lds(Gs + off, gr[i], 1.0f);
+        }
+        const uint32_t mbits = maskbits[cur.mrow + lq];
+        const int un = u + nwaves;
+        Unit nxt = cur;
+        if (un < n_units) { nxt = decode_unit(g, un); issue(nxt); }
+        lds_fence();
+
+        // recompute P (lane = query, regs = keys)
+        float s[16], p[16], ds[16];
+        {
+            f32x16 st = tile_xyT<HD, LDW>(Ks, Qs, lq, hh);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = st[r];
+        }
+        const uint32_t nz = masked_softmax<TRAIN>(s, p, mbits, hh, thr);
+        // dP^T[key][q] = V dO^T
+        {
+            f32x16 dp = tile_xyT<HD, LDW>(Vs, Gs, lq, hh);
+            float delta = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) delta += p[r] * dp[r];
+            delta += partner(delta);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ds[r] = ((nz >> r) & 1u) ? p[r] * (dp[r] - delta) : 0.f;
+        }
+        lds_fence();                                          // V tile is dead from here on
+        // transpose P and dS through LDS: write [q][key], later read [.][key = lane]
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            float* pp = Pt + lq * TW + 8 * gq + 4 * hh;
+            float* dd = Dt + lq * TW + 8 * gq + 4 * hh;
+            f32x2 a0 = {p[4 * gq], p[4 * gq + 1]}, a1 = {p[4 * gq + 2], p[4 * gq + 3]};
+            f32x2 b0 = {ds[4 * gq], ds[4 * gq + 1]}, b1 = {ds[4 * gq + 2], ds[4 * gq + 3]};
+            reinterpret_cast<f32x2*>(pp)[0] = a0; reinterpret_cast<f32x2*>(pp)[1] = a1;
+            reinterpret_cast<f32x2*>(dd)[0] = b0; reinterpret_cast<f32x2*>(dd)[1] = b1;
+        }
+        lds_fence();
+
+        f32x16 acc[NT];
+        T* gq_base = dqkv + cur.head * HD + lq * NT;
+        auto store_acc = [&](T* base, float mul) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float ov[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) ov[nt] = acc[nt][r] * mul;
+                store_nt<T, NT>(base + tok_of(cur, crow(r, hh)) * row3d, ov);
+            }
+        };
+        // dQ = scale * dS K        (A = dS in registers: lane = q)
+        tile_ay<HD, LDW>(ds, Ks, lq, hh, acc);
+        store_acc(gq_base, qk_scale<HD>());
+        // dK = dS^T (scale*Q)      (A = dS^T from scratch: lane = key; Qs already holds scale*Q)
+        float a[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[r] = Dt[crow(r, hh) * TW + lq];
+        tile_ay<HD, LDW>(a, Qs, lq, hh, acc);
+        store_acc(gq_base + g.d, 1.0f);
+        // dV = P^T dO
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[r] = Pt[crow(r, hh) * TW + lq];
+        tile_ay<HD, LDW>(a, Gs, lq, hh, acc);
+        store_acc(gq_base + 2 * g.d, 1.0f);
+        lds_fence();
+        cur = nxt;
+    }
+}
+
+__global__ void mfma_probe_k(const float* a, const float* b, float* out) {
+    const int lane = threadIdx.x;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    // A[i][k] supplied by lane (i = lane&31, k = lane>>5); B[k][j] by lane (j = lane&31, k = lane>>5)
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[(lane & 31) * 2 + (lane >> 5)], b[(lane >> 5) * 32 + (lane & 31)], acc, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) out[lane * 16 + i] = acc[i];
+}
+
+bool geom_ok(int B, int F, int nW, int nH, int hd) {
+    return B > 0 && F > 0 && (F % 2) == 0 && nW > 0 && nH > 0 && (hd == 32 || hd == 64 || hd == 128);
+}
+
+template <typename T, int HD>
+int launch_fwd(const void* qkv, void* o, const uint32_t* mb, const float* thr, WinGeom g, int n_units,
+               hipStream_t st) {
+    const int blocks = min((n_units + 3) / 4, 256 * 2);
+    if (thr)
+        win_attn_fwd_k<T, HD, true><<<blocks, 256, 0, st>>>((const T*)qkv, (T*)o, mb, thr, g, n_units);
+    else
+        win_attn_fwd_k<T, HD, false><<<blocks, 256, 0, st>>>((const T*)qkv, (T*)o, mb, thr, g, n_units);
+    HWGAT_LAUNCH_CHECK();
+}
+template <typename T, int HD>
+int launch_bwd(const void* qkv, const void* dO, void* dqkv, const uint32_t* mb, const float* thr,
+               WinGeom g, int n_units, hipStream_t st) {
+    constexpr int WAVES = HD <= 64 ? 4 : 2;                  // 4 x 34 KiB or 2 x 66 KiB of LDS per CU
+    const int blocks = min((n_units + WAVES - 1) / WAVES, 256);
+    if (thr)
+        win_attn_bwd_k<T, HD, true, WAVES><<<blocks, WAVES * 64, 0, st>>>((const T*)qkv, (const T*)dO, (T*)dqkv, mb, thr, g, n_units);
+    else
+        win_attn_bwd_k<T, HD, false, WAVES><<<blocks, WAVES * 64, 0, st>>>((const T*)qkv, (const T*)dO, (T*)dqkv, mb, thr, g, n_units);
+    HWGAT_LAUNCH_CHECK();
+}
+
+}  // namespace
+
+extern "C" int hwgat_debug_mfma32x32x2(const float* a, const float* b, float* out, void* stream) {
+    if (!a || !b || !out) return HWGAT_EINVAL;
+    mfma_probe_k<<<1, 64, 0, (hipStream_t)stream>>>(a, b, out);
+    HWGAT_LAUNCH_CHECK();
+}
+
+extern "C" int hwgat_win_attn_fwd(const void* qkv, void* o, const uint32_t* maskbits, const float* thr,
+                                  int B, int F, int nW, int nH, int hd, int shifted, int dtype,
+                                  void* stream) {
+    if (!qkv || !o || !maskbits) return HWGAT_EINVAL;
+    if (!geom_ok(B, F, nW, nH, hd)) return HWGAT_ESHAPE;
+    WinGeom g{F, nW * 16, nW, nH, F / 2, nH * hd, shifted ? 1 : 0};
+    const int64_t units = (int64_t)B * g.f * nW * nH;
+    if (units > 0x7fffffff) return HWGAT_ESHAPE;
+    hipStream_t st = (hipStream_t)stream;
+#define FWD(T)                                                                                  \
+    switch (hd) {                                                                               \
+        case 32: return launch_fwd<T, 32>(qkv, o, maskbits, thr, g, (int)units, st);            \
+        case 64: return launch_fwd<T, 64>(qkv, o, maskbits, thr, g, (int)units, st);            \
+        default: return launch_fwd<T, 128>(qkv, o, maskbits, thr, g, (int)units, st);           \
+    }
+    if (dtype == HWGAT_F32) { FWD(float) }
+    if (dtype == HWGAT_BF16) { FWD(bf16_t) }
+#undef FWD
+    return HWGAT_EDTYPE;
+}
+
+extern "C" int hwgat_win_attn_bwd(const void* qkv, const void* dO, void* dqkv, const uint32_t* maskbits,
+                                  const float* thr, int B, int F, int nW, int nH, int hd, int shifted,
+                                  int dtype, void* stream) {
+    if (!qkv || !dO || !dqkv || !maskbits) return HWGAT_EINVAL;
+    if (!geom_ok(B, F, nW, nH, hd)) return HWGAT_ESHAPE;
+    WinGeom g{F, nW * 16, nW, nH, F / 2, nH * hd, shifted ? 1 : 0};
+    const int64_t units = (int64_t)B * g.f * nW * nH;
+    if (units > 0x7fffffff) return HWGAT_ESHAPE;
+    hipStream_t st = (hipStream_t)stream;
+#define BWD(T)                                                                                        \
+    switch (hd) {                                                                                     \
+        case 32: return launch_bwd<T, 32>(qkv, dO, dqkv, maskbits, thr, g, (int)units, st);           \
+        case 64: return launch_bwd<T, 64>(qkv, dO, dqkv, maskbits, thr, g, (int)units, st);           \
+        default: return launch_bwd<T, 128>(qkv, dO, dqkv, maskbits, thr, g, (int)units, st);          \
+    }
+    if (dtype == HWGAT_F32) { BWD(float) }
+    if (dtype == HWGAT_BF16) { BWD(bf16_t) }
+#undef BWD
+    return HWGAT_EDTYPE;
+}

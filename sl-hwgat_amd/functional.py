@@ -1,0 +1,181 @@
+"""torch.autograd bindings of the HWGAT HIP kernels (thin: pointers + sizes).
+
+Every function here calls straight into libhwgat_hip.so through `_lib.call`;
+nothing falls back to torch arithmetic.  All activations are in the natural
+token order (B, F, K, d).
+"""
+import torch
+
+from . import _lib
+from ._lib import ptr, stream, dtype_code
+
+# Optional live kernel timing (bench.py): when TIMERS is a dict, every launcher call
+# is bracketed by HIP events recorded on the stream the kernel is launched on
+# (torch's current stream) and the (start, stop) pairs are appended per entry point.
+TIMERS = None
+
+
+def call(name, *args):
+    if TIMERS is None:
+        return _lib.call(name, *args)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    _lib.call(name, *args)
+    e1.record()
+    TIMERS.setdefault(name, []).append((e0, e1))
+
+
+def timers_summary():
+    """{entry point: (launches, total_ms)}; synchronises."""
+    torch.cuda.synchronize()
+    return {k: (len(v), sum(a.elapsed_time(b) for a, b in v)) for k, v in (TIMERS or {}).items()}
+
+
+# ---------------------------------------------------------------- mask rows
+def mask_bits(adj: torch.Tensor) -> torch.Tensor:
+    """(nW,32,32) 0/1 adjacency (reference model_params.py:373-392) -> the
+    (2,nW,32) uint32 rows `hwgat_win_attn_*` consume: [0] adjacency only,
+    [1] adjacency AND the last-slot shift mask (no cross-frame attention,
+    reference HWGATE.py:169-187)."""
+    a = adj.detach().to("cpu", torch.float32)
+    if a.dim() != 3 or a.shape[1:] != (32, 32):
+        raise ValueError("adjacency must be (nW, 32, 32) (temporal_patch_size 2 x window 16)")
+    if not bool(((a == 0) | (a == 1)).all()):
+        raise ValueError("adjacency must be a 0/1 matrix")
+    live = a != 0
+    same_frame = torch.zeros(32, 32, dtype=torch.bool)
+    same_frame[:16, :16] = True
+    same_frame[16:, 16:] = True
+    weights = (2 ** torch.arange(32, dtype=torch.int64))
+    plain = (live.to(torch.int64) * weights).sum(-1)
+    last = ((live & same_frame).to(torch.int64) * weights).sum(-1)
+    bits = torch.stack([plain, last])                               # (2,nW,32) in [0, 2^32)
+    bits = torch.where(bits >= 2 ** 31, bits - 2 ** 32, bits).to(torch.int32)
+    return bits.contiguous()
+
+
+# ---------------------------------------------------------------- embedding
+def embed(x, idx, bmat, pe, K, out_dtype=torch.float32):
+    """gather + Fourier features + PE (no gradient: B is frozen, PE a buffer)."""
+    B, T, J, C = x.shape
+    d0 = bmat.shape[0] * 2
+    out = torch.empty(B, T, K, d0, device=x.device, dtype=out_dtype)
+    call("hwgat_embed_fwd", ptr(x), ptr(idx), ptr(bmat), ptr(pe), ptr(out),
+         B, T, J, K, C, d0, dtype_code(out), stream())
+    return out
+
+
+# ---------------------------------------------------------------- LayerNorm
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta):
+        d = x.shape[-1]
+        n = x.numel() // d
+        y = torch.empty_like(x)
+        mean = torch.empty(n, device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        call("hwgat_ln_fwd", ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd),
+             n, d, dtype_code(x), stream())
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        d = x.shape[-1]
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dg = torch.zeros(2, d, device=x.device, dtype=torch.float32)
+        call("hwgat_ln_bwd", ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), None, ptr(dx),
+             ptr(dg[0]), ptr(dg[1]), x.numel() // d, d, dtype_code(x), stream())
+        return dx, dg[0], dg[1]
+
+
+def layer_norm(x, gamma, beta):
+    return _LayerNorm.apply(x.contiguous(), gamma, beta)
+
+
+# ---------------------------------------------------------------- attention
+class _WinAttn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, bits, thr, n_heads, shifted):
+        B, F, K, d3 = qkv.shape
+        d = d3 // 3
+        o = torch.empty(B, F, K, d, device=qkv.device, dtype=qkv.dtype)
+        call("hwgat_win_attn_fwd", ptr(qkv), ptr(o), ptr(bits), ptr(thr), B, F, K // 16, n_heads,
+             d // n_heads, int(shifted), dtype_code(qkv), stream())
+        ctx.save_for_backward(qkv, bits, thr)
+        ctx.cfg = (n_heads, int(shifted))
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, bits, thr = ctx.saved_tensors
+        n_heads, shifted = ctx.cfg
+        B, F, K, d3 = qkv.shape
+        d = d3 // 3
+        do = do.contiguous()
+        dqkv = torch.empty_like(qkv)
+        call("hwgat_win_attn_bwd", ptr(qkv), ptr(do), ptr(dqkv), ptr(bits), ptr(thr), B, F, K // 16,
+             n_heads, d // n_heads, shifted, dtype_code(qkv), stream())
+        return dqkv, None, None, None, None
+
+
+def window_attention(qkv, bits, thr, n_heads, shifted):
+    """qkv (B,F,K,3d) -> o (B,F,K,d).  `thr`: 1-element fp32 device tensor
+    (train mode) or None (eval mode)."""
+    return _WinAttn.apply(qkv.contiguous(), bits, thr, n_heads, shifted)
+
+
+# ---------------------------------------------------------------- merge
+class _Merge(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        B, F, K, d = x.shape
+        out = torch.empty(B, F // 2, K, 2 * d, device=x.device, dtype=x.dtype)
+        call("hwgat_merge", ptr(x), ptr(out), B, F, K, d, 0, dtype_code(x), stream())
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, f, K, d2 = dout.shape
+        dout = dout.contiguous()
+        dx = torch.empty(B, f * 2, K, d2 // 2, device=dout.device, dtype=dout.dtype)
+        call("hwgat_merge", ptr(dout), ptr(dx), B, f * 2, K, d2 // 2, 1, dtype_code(dout), stream())
+        return dx
+
+
+def temporal_merge(x):
+    return _Merge.apply(x.contiguous())
+
+
+# ---------------------------------------------------------------- LN + pool
+class _LnPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta):
+        B, d = x.shape[0], x.shape[-1]
+        n_tok = x.numel() // (B * d)
+        hat = torch.zeros(B, d, device=x.device, dtype=torch.float32)
+        mean = torch.empty(B * n_tok, device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        call("hwgat_lnpool_fwd", ptr(x), ptr(hat), ptr(mean), ptr(rstd), B, n_tok, d, dtype_code(x), stream())
+        hat_mean = hat / n_tok
+        ctx.save_for_backward(x, gamma, mean, rstd, hat_mean)
+        return hat_mean * gamma + beta
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        x, gamma, mean, rstd, hat_mean = ctx.saved_tensors
+        B, d = x.shape[0], x.shape[-1]
+        n_tok = x.numel() // (B * d)
+        dfeat = dfeat.float()
+        g = (dfeat * gamma / n_tok).contiguous()
+        dx = torch.empty_like(x)
+        call("hwgat_lnpool_bwd", ptr(g), ptr(x), ptr(mean), ptr(rstd), ptr(dx), B, n_tok, d,
+             dtype_code(x), stream())
+        return dx, (dfeat * hat_mean).sum(0), dfeat.sum(0)
+
+
+def ln_mean_pool(x, gamma, beta):
+    """final LayerNorm + mean over all tokens -> (B, d) fp32."""
+    return _LnPool.apply(x.contiguous(), gamma, beta)

@@ -1,0 +1,190 @@
+"""HWGAT (hierarchical windowed graph attention) -- MI355X-native backend.
+
+Drop-in for the reference's `hwgat/models/HWGATE.py`: class `Model` takes the
+same positional 16-tuple (`HWGATEParams.get_model_params()`), has the same
+`forward(x: (B,T,K,C)) -> (B,num_classes)`, is an `nn.Module` that takes part
+in autograd, and exposes the same `state_dict()` keys/shapes,
+so reference checkpoints load here and vice versa.
+
+Inside, nothing is shared with the reference's formulation: activations stay
+in natural (B,F,K,d) order for the whole network, window partition / reverse /
+roll never materialise, and the attention core, LayerNorms, embedding, merging
+and final pooling run as hand-written gfx950 kernels (libhwgat_hip.so).  There
+is no CPU path: constructing on / moving to a CPU device works (parameters are
+ordinary tensors) but `forward` needs an MI355X.
+"""
+import math
+from typing import List, Optional
+
+import torch
+from torch import nn
+import torch.nn.functional as tF
+
+from .. import functional as HF
+
+_SUPPORTED_WIDTHS = (128, 256, 512, 1024)
+
+
+class _Slot(nn.Module):
+    """parameter container (no forward of its own)"""
+
+
+def _sinusoid(max_len, d):
+    pe = torch.zeros(max_len, d)
+    pos = torch.arange(0, max_len).unsqueeze(1)
+    div = torch.exp(torch.arange(0, d, 2) * -(math.log(10000.0) / d))
+    pe[:, 0::2] = torch.sin(pos * div)
+    pe[:, 1::2] = torch.cos(pos * div)
+    return pe.view(1, max_len, 1, d)
+
+
+def _last_slot_mask(frames, n_windows):
+    """value of the reference's `attn_mask` buffer (HWGATE.py:169-187): all
+    ones except the last temporal slot, which is block-diagonal per frame."""
+    f = frames // 2
+    m = torch.ones(f, n_windows, 32, 32)
+    blk = torch.zeros(32, 32)
+    blk[:16, :16] = 1
+    blk[16:, 16:] = 1
+    m[f - 1] = blk
+    return m.view(f * n_windows, 32, 32)
+
+
+class Model(nn.Module):
+    def __init__(self, kp_dim=26, num_kps=64, temporal_dim=256, num_classes=1000, embed_dim=64,
+                 temporal_patch_size=4, pe=False, depths=[2, 2, 6, 2], num_heads=[2, 4, 8, 16],
+                 window_size=16, adj_mat=None, drop_rate=0., attn_drop_rate=0., ff_ratio=4.,
+                 norm_layer=nn.LayerNorm, device=None) -> None:
+        super().__init__()
+        if temporal_patch_size != 2:
+            # the reference's TemporalMerging doubles the width per stage, which is only
+            # consistent with temporal_patch_size == 2 (HWGATE.py:61 vs :312)
+            raise NotImplementedError("HWGAT HIP backend supports temporal_patch_size == 2")
+        if window_size != 16:
+            raise NotImplementedError("HWGAT HIP backend supports window_size == 16")
+        if attn_drop_rate != 0.0:
+            raise NotImplementedError("attn_drop_rate must be 0 (the reference default)")
+        if norm_layer is not nn.LayerNorm:
+            raise NotImplementedError("norm_layer must be nn.LayerNorm")
+        assert num_kps % window_size == 0, "window size and number of kps are incompatible"
+        n_stage = len(depths)
+        assert temporal_dim % (2 ** n_stage) == 0, "temporal dimension must be divisible by 2**stages"
+        assert embed_dim % 2 == 0
+        self.kp_dim, self.num_kps, self.temporal_dim = kp_dim, num_kps, temporal_dim
+        self.num_classes, self.embed_dim, self.pe = num_classes, embed_dim, pe
+        self.depths, self.num_heads = list(depths), list(num_heads)
+        self.drop_rate, self.ff_ratio = float(drop_rate), ff_ratio
+        self.num_layers = n_stage
+        self.num_features = int(embed_dim * 2 ** (n_stage - 1))
+        self.n_windows = num_kps // 16
+
+        self.B = nn.Parameter(torch.normal(0.0, 1.0, (embed_dim // 2, kp_dim)) * 10, requires_grad=False)
+        if pe:
+            self.pos_encoder = _Slot()
+            self.pos_encoder.register_buffer("pe", _sinusoid(temporal_dim, embed_dim))
+
+        self.layers = nn.ModuleList()
+        for i in range(n_stage):
+            d = embed_dim * 2 ** i
+            if d not in _SUPPORTED_WIDTHS or d % num_heads[i] or (d // num_heads[i]) not in (32, 64, 128):
+                raise NotImplementedError(f"stage width {d} / heads {num_heads[i]} not supported by the HIP kernels")
+            stage = _Slot()
+            stage.blocks = nn.ModuleList()
+            for j in range(depths[i]):
+                blk = _Slot()
+                blk.norm1 = nn.LayerNorm(d)
+                blk.attn = _Slot()
+                blk.attn.qkv = nn.Linear(d, 3 * d)
+                blk.attn.proj = nn.Linear(d, d)
+                blk.norm2 = nn.LayerNorm(d)
+                blk.ff = _Slot()
+                blk.ff.fc1 = nn.Linear(d, int(d * ff_ratio))
+                blk.ff.fc2 = nn.Linear(int(d * ff_ratio), d)
+                blk.register_buffer("attn_mask", _last_slot_mask(temporal_dim // 2 ** i, self.n_windows)
+                                    if j % 2 == 1 else None)
+                stage.blocks.append(blk)
+            self.layers.append(stage)
+        self.norm = nn.LayerNorm(self.num_features)
+        self.head = nn.Linear(self.num_features, num_classes) if num_classes > 0 else nn.Identity()
+
+        for m in self.modules():                       # reference HWGATE.py:333-340
+            if isinstance(m, nn.Linear):
+                nn.init.trunc_normal_(m.weight, std=.02)
+                nn.init.zeros_(m.bias)
+
+        if adj_mat is None:
+            adj_mat = torch.ones(self.n_windows, 32, 32)
+        self.adj_mat = adj_mat
+        # compact bit rows derived from adjacency + shift structure; not part of state_dict
+        self.register_buffer("_mask_bits", HF.mask_bits(adj_mat), persistent=False)
+        self.part_index: Optional[torch.Tensor] = None           # set by use_part_table()
+        self.activation_dtype = torch.float32
+        self.threshold_override: Optional[List[float]] = None    # tests: inject train thresholds
+        if device is not None:
+            self.to(device)
+
+    # ------------------------------------------------------------ options
+    def use_part_table(self, index: torch.Tensor):
+        """accept raw (B,T,J,C) keypoints and gather joints on the device
+        (replaces the host-side WindowCreate transform)."""
+        assert index.numel() == self.num_kps
+        self.register_buffer("_part_index", index.to(torch.int32).to(self.B.device), persistent=False)
+        self.part_index = self._part_index
+        return self
+
+    def set_activation_dtype(self, dtype):
+        assert dtype in (torch.float32, torch.bfloat16)
+        self.activation_dtype = dtype
+        return self
+
+    # ------------------------------------------------------------ forward
+    def _linear(self, x, lin):
+        if x.dtype == torch.float32:
+            return tF.linear(x, lin.weight, lin.bias)
+        return tF.linear(x, lin.weight.to(x.dtype), lin.bias.to(x.dtype))
+
+    def _drop(self, x):
+        if self.training and self.drop_rate > 0.0:
+            return tF.dropout(x, self.drop_rate, True)
+        return x
+
+    def _block(self, h, blk, n_heads, shifted, thr):
+        xn = HF.layer_norm(h, blk.norm1.weight, blk.norm1.bias)
+        qkv = self._linear(xn, blk.attn.qkv)
+        o = HF.window_attention(qkv, self._mask_bits, thr, n_heads, shifted)
+        y = h + self._drop(self._linear(o, blk.attn.proj))
+        z = HF.layer_norm(y, blk.norm2.weight, blk.norm2.bias)
+        u = self._drop(tF.gelu(self._linear(z, blk.ff.fc1)))
+        return y + self._drop(self._linear(u, blk.ff.fc2))
+
+    def forward_features(self, x):
+        if x.dim() != 4 or x.shape[1] != self.temporal_dim or x.shape[3] != self.kp_dim:
+            raise ValueError(f"expected (B,{self.temporal_dim},K,{self.kp_dim}) keypoints, got {tuple(x.shape)}")
+        idx = None
+        if x.shape[2] != self.num_kps:
+            if self.part_index is None:
+                raise ValueError(f"got {x.shape[2]} joints, model has {self.num_kps} slots and no part table")
+            idx = self.part_index
+        x = x.contiguous().float()
+        pe = self.pos_encoder.pe.view(self.temporal_dim, self.embed_dim) if self.pe else None
+        h = HF.embed(x, idx, self.B, pe, self.num_kps, self.activation_dtype)
+        if self.pe:
+            h = self._drop(h)
+        k = 0
+        for i, stage in enumerate(self.layers):
+            for j, blk in enumerate(stage.blocks):
+                thr = None
+                if self.training:
+                    if self.threshold_override is not None:
+                        thr = torch.full((1,), float(self.threshold_override[k]), device=x.device)
+                    else:
+                        thr = torch.rand(1, device=x.device)      # device RNG, no host sync
+                h = self._block(h, blk, self.num_heads[i], j % 2 == 1, thr)
+                k += 1
+            if i < self.num_layers - 1:
+                h = HF.temporal_merge(h)
+        return HF.ln_mean_pool(h, self.norm.weight, self.norm.bias)
+
+    def forward(self, x):
+        feat = self.forward_features(x)
+        return self.head(feat)

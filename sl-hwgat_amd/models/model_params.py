@@ -1,0 +1,62 @@
+"""Hyper-parameters + part-graph adjacency for the MI355X HWGAT backend.
+
+Drop-in for `HWGATEParams` of the reference (hwgat/models/model_params.py:
+243-403): same attribute names, same defaults, same positional tuple from
+`get_model_params()`, so `configs.py:80-82` / `utils.py:55-59` work unchanged.
+"""
+import numpy as np
+import torch
+from torch import nn
+
+# undirected edges of one 16-slot part window [3 head | 3 arm | 10 hand]
+# (reference model_params.py:261-287; its four per-window lists are identical)
+_PART_EDGES = [(0, 1), (0, 2), (0, 3), (3, 4), (4, 5), (5, 6), (6, 7), (6, 8), (8, 9), (8, 10),
+               (6, 10), (10, 11), (10, 12), (6, 12), (12, 13), (12, 14), (14, 15), (6, 14),
+               (7, 9), (9, 11), (11, 13), (13, 15), (7, 15), (7, 11), (7, 13)]
+
+
+class HWGATEParams:
+    def __init__(self, dataset_params, input_dim, device=None, num_kps=64, embed_dim=128):
+        self.kp_dim = input_dim
+        self.num_kps = num_kps                      # nW * 16; reference default 64
+        self.temporal_dim = dataset_params['src_len']
+        self.num_classes = dataset_params['num_class']
+        self.embed_dim = embed_dim
+        self.temporal_patch_size = 2
+        self.pe = True
+        self.depths = [2, 2, 4]
+        self.num_heads = [2, 4, 8]
+        self.window_size = 16
+        self.drop_rate = 0.1
+        self.attn_drop_rate = 0.0
+        self.ff_ratio = 2.
+        self.norm_layer = nn.LayerNorm
+        self.device = device
+        self.edges = [[list(e) for e in _PART_EDGES] for _ in range(self.num_kps // self.window_size)]
+        self.adj_mat = torch.tensor(self.get_adj_mat(), dtype=torch.float32)
+
+    def get_adj(self, index):
+        """I + symmetric part graph of window `index` (W x W)."""
+        a = np.eye(self.window_size)
+        e = np.asarray(self.edges[index])
+        a[e[:, 0], e[:, 1]] = 1
+        a[e[:, 1], e[:, 0]] = 1
+        return a
+
+    def get_adj_mat(self):
+        """(nW, TP*W, TP*W): same frame -> part graph, neighbouring frame ->
+        same joint only, further frames -> nothing."""
+        TP, W = self.temporal_patch_size, self.window_size
+        frame_gap = np.abs(np.arange(TP)[:, None] - np.arange(TP)[None, :])
+        out = []
+        for w in range(self.num_kps // W):
+            blocks = np.where(frame_gap[:, :, None, None] == 0, self.get_adj(w),
+                              np.where(frame_gap[:, :, None, None] == 1, np.eye(W), 0.0))
+            out.append(blocks.transpose(0, 2, 1, 3).reshape(TP * W, TP * W))
+        return np.array(out)
+
+    def get_model_params(self):
+        return (self.kp_dim, self.num_kps, self.temporal_dim, self.num_classes, self.embed_dim,
+                self.temporal_patch_size, self.pe, self.depths, self.num_heads, self.window_size,
+                self.adj_mat, self.drop_rate, self.attn_drop_rate, self.ff_ratio, self.norm_layer,
+                self.device)

@@ -1,0 +1,237 @@
+"""GPU parity: every HIP kernel (through the C-ABI) vs the fp64 oracle on seeded inputs.
+
+fp32 kernels: bound 1e-3 relative (north_star), observed ~1e-6; bf16 storage: 1e-2.
+"""
+import importlib
+
+import pytest
+import torch
+
+from oracle import hwgat_oracle as O
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+hw = importlib.import_module("sl-hwgat_amd")
+HF = hw.functional
+DEV = "cuda:0"
+F32_TOL, BF16_TOL = 2e-5, 1e-2
+
+
+def _oracle_attn(qkv, adj, n_heads, shifted, thr):
+    """natural-order qkv (B,F,K,3d) fp64 -> o (B,F,K,d) with the oracle's
+    roll / partition / attention / reverse / roll chain"""
+    B, F, K, d3 = qkv.shape
+    d, nW = d3 // 3, K // 16
+    hd = d // n_heads
+    x = torch.roll(qkv, -1, 1) if shifted else qkv
+    w = O.to_windows(x)                                             # (B,f,nW,32,3d)
+    w = w.reshape(B, F // 2, nW, 32, 3, n_heads, hd).permute(4, 0, 1, 2, 5, 3, 6)
+    sm = O.shift_mask(F, nW, 2, 1, qkv.dtype).view(F // 2, nW, 32, 32) if shifted else None
+    o, _ = O.window_attention(w[0], w[1], w[2], adj.to(qkv.dtype), sm, thr)
+    o = O.from_windows(o)
+    return torch.roll(o, 1, 1) if shifted else o
+
+
+def test_mfma_operand_layout():
+    g = torch.Generator().manual_seed(0)
+    a = torch.randint(-4, 5, (32, 2), generator=g).float()
+    b = torch.randint(-4, 5, (2, 32), generator=g).float()          # asymmetric on purpose
+    out = torch.empty(64, 16, device=DEV)
+    ad, bd = a.to(DEV), b.to(DEV)                                   # keep alive across the launch
+    hw._lib.call("hwgat_debug_mfma32x32x2", hw._lib.ptr(ad), hw._lib.ptr(bd), hw._lib.ptr(out), hw._lib.stream())
+    out = out.cpu()
+    d = a @ b
+    for lane in range(64):
+        for r in range(16):
+            row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+            assert out[lane, r] == d[row, lane & 31], (lane, r)
+
+
+@pytest.mark.parametrize("hd,nH,nW,F,B", [(64, 2, 2, 8, 2), (64, 4, 5, 4, 3), (128, 2, 1, 6, 2), (32, 4, 3, 4, 1)])
+@pytest.mark.parametrize("shifted", [False, True])
+@pytest.mark.parametrize("thr", [None, 0.07, 0.0005, 0.9999])
+def test_window_attention_fwd_bwd(hd, nH, nW, F, B, shifted, thr):
+    g = torch.Generator().manual_seed(hd + nW + F)
+    d, K = nH * hd, nW * 16
+    qkv = torch.randn(B, F, K, 3 * d, generator=g) * 0.8
+    do = torch.randn(B, F, K, d, generator=g)
+    adj = O.window_adjacency(nW)
+    bits = HF.mask_bits(adj).to(DEV)
+    thr_t = None if thr is None else torch.tensor([thr], device=DEV)
+
+    ref_in = qkv.double().requires_grad_(True)
+    ref = _oracle_attn(ref_in, adj, nH, shifted, thr)
+    ref.backward(do.double())
+
+    x = qkv.to(DEV).requires_grad_(True)
+    out = HF.window_attention(x, bits, thr_t, nH, shifted)
+    out.backward(do.to(DEV))
+    assert rel_err(out.detach().cpu(), ref.detach()) < F32_TOL
+    assert rel_err(x.grad.cpu(), ref_in.grad) < F32_TOL
+
+    # bf16 storage (config 3): same math, bf16 in/out
+    xb = qkv.to(DEV, torch.bfloat16).requires_grad_(True)
+    refb_in = xb.detach().cpu().double().requires_grad_(True)
+    refb = _oracle_attn(refb_in, adj, nH, shifted, thr)
+    refb.backward(do.double())
+    outb = HF.window_attention(xb, bits, thr_t, nH, shifted)
+    outb.backward(do.to(DEV, torch.bfloat16))
+    if thr is None or thr > 0.9:          # threshold selectors can flip under bf16 rounding of S
+        assert rel_err(outb.detach().float().cpu(), refb.detach()) < BF16_TOL
+        assert rel_err(xb.grad.float().cpu(), refb_in.grad) < 2 * BF16_TOL
+
+
+def test_window_attention_edge_rows():
+    """exact-zero logits and fully masked rows (SURVEY 8a consequences i-iii)"""
+    g = torch.Generator().manual_seed(5)
+    B, F, nW, nH, hd = 1, 4, 2, 2, 64
+    d, K = nH * hd, nW * 16
+    qkv = torch.randn(B, F, K, 3 * d, generator=g)
+    qkv[0, 0, 3, :d] = 0.0            # a query row of zeros -> all its logits are exactly 0 -> uniform 1/32
+    qkv[0, 1, 5, d:2 * d] = 0.0       # a key row of zeros  -> that key's logit is exactly 0 for every query
+    adj = O.window_adjacency(nW)
+    bits = HF.mask_bits(adj).to(DEV)
+    for shifted in (False, True):
+        for thr in (None, 1e-6):      # thr ~ 0 drops everything: every row uniform over all 32 keys
+            ref_in = qkv.double().requires_grad_(True)
+            ref = _oracle_attn(ref_in, adj, nH, shifted, thr)
+            ref.sum().backward()
+            x = qkv.to(DEV).requires_grad_(True)
+            t = None if thr is None else torch.tensor([thr], device=DEV)
+            out = HF.window_attention(x, bits, t, nH, shifted)
+            out.sum().backward()
+            assert rel_err(out.detach().cpu(), ref.detach()) < F32_TOL, (shifted, thr)
+            assert (x.grad.cpu() - ref_in.grad).abs().max() < 1e-5, (shifted, thr)
+    # uniform row really is the mean of V over the whole window
+    out = HF.window_attention(qkv.to(DEV), bits, None, nH, False).cpu()
+    v = qkv[0, 0:2, 0:16, 2 * d:].reshape(32, d)
+    assert torch.allclose(out[0, 0, 3], v.mean(0), atol=1e-5)
+
+
+@pytest.mark.parametrize("d", [128, 256, 512, 1024])
+def test_layer_norm_fwd_bwd(d):
+    g = torch.Generator().manual_seed(d)
+    for n in (7, 64, 1000):
+        x = torch.randn(n, d, generator=g) * 2 + 0.5
+        w, b = torch.randn(d, generator=g), torch.randn(d, generator=g)
+        dy = torch.randn(n, d, generator=g)
+        xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+        O.layer_norm(xr, wr, br).backward(dy.double())
+        xg, wg, bg = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+        y = HF.layer_norm(xg, wg, bg)
+        y.backward(dy.to(DEV))
+        assert rel_err(y.detach().cpu(), O.layer_norm(x.double(), w.double(), b.double())) < F32_TOL
+        assert rel_err(xg.grad.cpu(), xr.grad) < F32_TOL
+        assert rel_err(wg.grad.cpu(), wr.grad) < F32_TOL
+        assert rel_err(bg.grad.cpu(), br.grad) < F32_TOL
+        xb = x.to(DEV, torch.bfloat16)
+        yb = HF.layer_norm(xb, wg.detach(), bg.detach())
+        assert rel_err(yb.float().cpu(), O.layer_norm(xb.cpu().double(), w.double(), b.double())) < BF16_TOL
+
+
+def test_ln_bwd_residual_argument():
+    g = torch.Generator().manual_seed(1)
+    n, d = 50, 256
+    x, dy, res = (torch.randn(n, d, generator=g).to(DEV) for _ in range(3))
+    w = torch.randn(d, generator=g).to(DEV)
+    mean, rstd = torch.empty(n, device=DEV), torch.empty(n, device=DEV)
+    y = torch.empty_like(x)
+    L = hw._lib
+    L.call("hwgat_ln_fwd", L.ptr(x), L.ptr(w), L.ptr(w), L.ptr(y), L.ptr(mean), L.ptr(rstd), n, d, 0, L.stream())
+    dx0, dx1 = torch.empty_like(x), torch.empty_like(x)
+    dg = torch.zeros(4, d, device=DEV)
+    L.call("hwgat_ln_bwd", L.ptr(dy), L.ptr(x), L.ptr(mean), L.ptr(rstd), L.ptr(w), None, L.ptr(dx0),
+           L.ptr(dg[0]), L.ptr(dg[1]), n, d, 0, L.stream())
+    L.call("hwgat_ln_bwd", L.ptr(dy), L.ptr(x), L.ptr(mean), L.ptr(rstd), L.ptr(w), L.ptr(res), L.ptr(dx1),
+           L.ptr(dg[2]), L.ptr(dg[3]), n, d, 0, L.stream())
+    assert torch.allclose(dx1, dx0 + res, atol=1e-6)
+    assert torch.equal(dg[0], dg[2]) or torch.allclose(dg[0], dg[2], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("C,d0,J,nW", [(2, 128, 29, 4), (3, 256, 133, 7), (2, 128, 32, 2)])
+def test_embed(C, d0, J, nW):
+    g = torch.Generator().manual_seed(C * 7 + nW)
+    B, T, K = 2, 8, nW * 16
+    x = torch.rand(B, T, J, C, generator=g)
+    bmat = torch.randn(d0 // 2, C, generator=g) * 10
+    pe = O.sinusoid_table(T, d0)
+    idx = hw.part_table(J, nW) if J != K else None
+    xs = x[:, :, idx.long()] if idx is not None else x
+    # the fp32 oracle is the comparison point here: the argument 2*pi*x.B is itself only
+    # fp32-accurate (|arg| ~ 1e2 rad -> abs error ~1e-5), so compare with an absolute bound
+    ref = O.fourier_embed(xs, bmat) + pe[:, :T]
+    out = HF.embed(x.to(DEV), None if idx is None else idx.to(DEV), bmat.to(DEV),
+                   pe.view(T, d0).to(DEV), K)
+    assert (out.cpu() - ref).abs().max() < 2e-4
+    ref64 = O.fourier_embed(xs.double(), bmat.double()) + pe[:, :T].double()
+    assert (out.cpu().double() - ref64).abs().max() < 2e-4
+    out_nope = HF.embed(x.to(DEV), None if idx is None else idx.to(DEV), bmat.to(DEV), None, K)
+    assert (out_nope.cpu() - O.fourier_embed(xs, bmat)).abs().max() < 2e-4
+
+
+def test_merge_roundtrip():
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 8, 32, 128, generator=g)
+    ref = x.reshape(2, 4, 2, 32, 128).transpose(2, 3).reshape(2, 4, 32, 256)
+    xg = x.to(DEV).requires_grad_(True)
+    out = HF.temporal_merge(xg)
+    assert torch.equal(out.detach().cpu(), ref)
+    out.backward(out.detach())
+    assert torch.equal(xg.grad.cpu(), x)
+    xb = x.to(DEV, torch.bfloat16)
+    assert torch.equal(HF.temporal_merge(xb).cpu(), ref.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("d,n_tok,B", [(512, 640, 3), (128, 37, 2), (1024, 16, 1)])
+def test_ln_mean_pool(d, n_tok, B):
+    g = torch.Generator().manual_seed(d + n_tok)
+    x = torch.randn(B, n_tok, d, generator=g) * 1.5
+    w, b = torch.randn(d, generator=g), torch.randn(d, generator=g)
+    df = torch.randn(B, d, generator=g)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    ref = O.layer_norm(xr, wr, br).mean(1)
+    ref.backward(df.double())
+    xg, wg, bg = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+    out = HF.ln_mean_pool(xg, wg, bg)
+    out.backward(df.to(DEV))
+    assert rel_err(out.detach().cpu(), ref.detach()) < F32_TOL
+    assert rel_err(xg.grad.cpu(), xr.grad) < F32_TOL
+    assert rel_err(wg.grad.cpu(), wr.grad) < 1e-4
+    assert rel_err(bg.grad.cpu(), br.grad) < F32_TOL
+
+
+def test_full_size_properties_config2():
+    """BASELINE config 2 (B64 T128 K80 d128): size-independent properties of the
+    attention kernel where the oracle would take minutes."""
+    B, F, nW, nH, hd = 64, 128, 5, 2, 64
+    d, K = nH * hd, nW * 16
+    g = torch.Generator(device=DEV).manual_seed(0)
+    qkv = torch.randn(B, F, K, 3 * d, device=DEV, generator=g)
+    bits = HF.mask_bits(O.window_adjacency(nW)).to(DEV)
+    for shifted in (False, True):
+        # (1) rows of P sum to 1: V == 1 -> O == 1 everywhere
+        q1 = qkv.clone()
+        q1[..., 2 * d:] = 1.0
+        o = HF.window_attention(q1, bits, None, nH, shifted)
+        assert (o - 1).abs().max() < 1e-5
+        # (2) linear in V
+        a = HF.window_attention(qkv, bits, None, nH, shifted)
+        q2 = qkv.clone()
+        q2[..., 2 * d:] *= -2.0
+        b2 = HF.window_attention(q2, bits, None, nH, shifted)
+        assert (b2 + 2 * a).abs().max() < 1e-4
+        # (3) clips are independent: a batch permutation permutes the output
+        perm = torch.randperm(B, device=DEV)
+        assert torch.equal(HF.window_attention(qkv[perm].contiguous(), bits, None, nH, shifted), a[perm])
+        # (4) a sampled clip agrees with the oracle
+        ref = _oracle_attn(qkv[7:8, :8].cpu().double(), O.window_adjacency(nW), nH, False, None)
+        if not shifted:
+            got = HF.window_attention(qkv[7:8, :8].contiguous(), bits, None, nH, False)
+            assert rel_err(got.cpu(), ref) < F32_TOL
+    # backward: sum over dqkv of V-part equals P^T dO column sums -> with dO == 1, dV sums to 32 per window/channel
+    x = qkv.clone().requires_grad_(True)
+    HF.window_attention(x, bits, None, nH, False).sum().backward()
+    dv = x.grad[..., 2 * d:]
+    per_window = dv.view(B, F // 2, 2, nW, 16, d).sum(dim=(2, 4))
+    assert (per_window - 32).abs().max() < 1e-3
+    assert x.grad[..., :2 * d].abs().max() < 1e-4         # dO == const -> dS == 0 -> dq = dk = 0
