@@ -234,4 +234,10 @@ def test_full_size_properties_config2():
     dv = x.grad[..., 2 * d:]
     per_window = dv.view(B, F // 2, 2, nW, 16, d).sum(dim=(2, 4))
     assert (per_window - 32).abs().max() < 1e-3
-    assert x.grad[..., :2 * d].abs().max() < 1e-4         # dO == const -> dS == 0 -> dq = dk = 0
+    # rows of dS sum to zero: with every key vector identical (k == 1) dq = scale * rowsum(dS) * 1 = 0
+    x = qkv.clone()
+    x[..., d:2 * d] = 1.0
+    x.requires_grad_(True)
+    g2 = torch.randn(B, F, K, d, device=DEV, generator=g)
+    HF.window_attention(x, bits, None, nH, True).backward(g2)
+    assert x.grad[..., :d].abs().max() < 1e-3
