@@ -59,7 +59,8 @@ int hwgat_embed_fwd(const float* x, const int32_t* idx, const float* bmat, const
 
 /* ---- LayerNorm over the last axis (HWGATE.py:203, 219, 353), eps 1e-5.
  *   x, y (N, d) `dtype`; gamma, beta (d) fp32; mean, rstd (N) fp32 (saved
- *   for backward).  d in {128, 256, 512, 1024}. */
+ *   for backward).  d in {128, 256, 512, 1024}.  y may be NULL: statistics only
+ *   (the fused linears normalise on the fly from mean/rstd). */
 int hwgat_ln_fwd(const void* x, const float* gamma, const float* beta, void* y,
                  float* mean, float* rstd, int64_t N, int d, int dtype, void* stream);
 
@@ -107,6 +108,37 @@ int hwgat_lnpool_bwd(const float* g, const void* x, const float* mean, const flo
  * out[b,fi,k,tp*d+c] = in[b,2fi+tp,k,c]; `inverse` = 1 maps gradients back. */
 int hwgat_merge(const void* in, void* out, int B, int F, int K, int d, int inverse,
                 int dtype, void* stream);
+
+/* ---- a-6/a-7/a-8: fp32 Linear layers on f32 MFMA with fused elementwise work.
+ * Replaces nn.Linear (HWGATE.py:86,115,131,134) + bias + GELU (:132) + Dropout
+ * (:116,:133,:135) + residual adds (:217,:219) forward, and their dX backward.
+ *   C[M,N] = pro(A)[M,K] . W[N,K]^T, all fp32 row-major; M % 128 == N % 128 == K % 32 == 0.
+ *   pro: 0 none | 1 LayerNorm: (A-mean[m])*rstd[m]*gamma[k]+beta[k] | 2 dropout mask on A
+ *        (keep-scale 1/(1-pro_p), element index m*K+k, seed pro_seed)
+ *   epi: 0  C = acc + bias
+ *        1  C = res + dropout(acc + bias)             (mask index m*N+n, seed epi_seed)
+ *        2  C2 = acc + bias ; C = dropout(gelu(C2))   (exact-erf GELU)
+ *        3  C = acc * dropmask * gelu'(aux)           (backward of epi 2; aux = saved C2)
+ *        4  C = acc
+ *   bias may be NULL (treated as 0).  For dX pass W = transposed weight. */
+int hwgat_linear_nt_f32(const float* A, const float* W, const float* bias, float* C, int64_t M, int N,
+                        int K, int pro, const float* mean, const float* rstd, const float* gamma,
+                        const float* beta, uint32_t pro_seed, float pro_p, int epi, const float* res,
+                        float* C2, const float* aux, uint32_t epi_seed, float epi_p, void* stream);
+
+/* weight/bias gradient: dW[N,K] += dropmask(A)[M,N]^T . ln(B)[M,K] ; db[N] += colsum(dropmask(A))
+ * (db may be NULL).  Accumulates with fp32 atomics across M slices: caller provides zeroed
+ * (or to-be-accumulated-into) dW/db.  M % 32 == N % 128 == K % 128 == 0.  pro_p == 0: no mask.
+ * mean != NULL: B is LayerNorm-ed on the fly, (B-mean[m])*rstd[m]*gamma[k]+beta[k]. */
+int hwgat_linear_tn_f32(const float* A, const float* B, float* dW, float* db, int64_t M, int N, int K,
+                        uint32_t pro_seed, float pro_p, const float* mean, const float* rstd,
+                        const float* gamma, const float* beta, void* stream);
+
+/* out[C,R] = in[R,C]^T (used on weights only) */
+int hwgat_transpose_f32(const float* in, float* out, int R, int C, void* stream);
+
+/* the dropout mask the fused kernels use: out[i] = keep(seed, i) ? 1/(1-p) : 0 */
+int hwgat_dropout_mask_f32(float* out, int64_t n, uint32_t seed, float p, void* stream);
 
 #ifdef __cplusplus
 }

@@ -19,6 +19,7 @@ _ERR = {-1: "HWGAT_EINVAL (null pointer / bad size)", -2: "HWGAT_ESHAPE (unsuppo
         -3: "HWGAT_EDTYPE (unknown dtype)"}
 
 _P, _I, _L = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+_U, _F = ctypes.c_uint32, ctypes.c_float
 _SIGS = {
     "hwgat_abi_version": [],
     "hwgat_debug_mfma32x32x2": [_P, _P, _P, _P],
@@ -30,6 +31,10 @@ _SIGS = {
     "hwgat_lnpool_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "hwgat_lnpool_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "hwgat_merge": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "hwgat_linear_nt_f32": [_P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _P, _U, _F, _I, _P, _P, _P, _U, _F, _P],
+    "hwgat_linear_tn_f32": [_P, _P, _P, _P, _L, _I, _I, _U, _F, _P, _P, _P, _P, _P],
+    "hwgat_transpose_f32": [_P, _P, _I, _I, _P],
+    "hwgat_dropout_mask_f32": [_P, _L, _U, _F, _P],
 }
 _lib = None
 

@@ -74,11 +74,13 @@ __global__ __launch_bounds__(256) void ln_fwd_k(const T* __restrict__ x, const f
         load_row<T, D>(x + r * D, sub, v);
         float mean, rstd;
         row_stats<D>(v, mean, rstd);
+        if (y != nullptr) {                        // y == NULL: statistics only (fused consumers normalise on the fly)
 #pragma unroll
-        for (int c = 0; c < M::CPL; ++c)
+            for (int c = 0; c < M::CPL; ++c)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[c][e] = (v[c][e] - mean) * rstd * g[c][e] + b[c][e];
-        store_row<T, D>(y + r * D, sub, v);
+                for (int e = 0; e < 4; ++e) v[c][e] = (v[c][e] - mean) * rstd * g[c][e] + b[c][e];
+            store_row<T, D>(y + r * D, sub, v);
+        }
         if (sub == 0) { mean_o[r] = mean; rstd_o[r] = rstd; }
     }
 }
@@ -300,7 +302,7 @@ inline int pool_chunks(int B, int n_tok) {
 
 extern "C" int hwgat_ln_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
                             float* rstd, int64_t N, int d, int dtype, void* stream) {
-    if (!x || !gamma || !beta || !y || !mean || !rstd || N <= 0) return HWGAT_EINVAL;
+    if (!x || !gamma || !beta || !mean || !rstd || N <= 0) return HWGAT_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == HWGAT_F32) return ln_fwd_t<float>(x, gamma, beta, y, mean, rstd, N, d, st);
     if (dtype == HWGAT_BF16) return ln_fwd_t<bf16_t>(x, gamma, beta, y, mean, rstd, N, d, st);

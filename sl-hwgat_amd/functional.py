@@ -179,3 +179,68 @@ class _LnPool(torch.autograd.Function):
 def ln_mean_pool(x, gamma, beta):
     """final LayerNorm + mean over all tokens -> (B, d) fp32."""
     return _LnPool.apply(x.contiguous(), gamma, beta)
+
+
+# ---------------------------------------------------------------- fp32 MFMA linears
+PRO_NONE, PRO_LN, PRO_DROP = 0, 1, 2
+EPI_BIAS, EPI_BIAS_DROP_RES, EPI_BIAS_GELU_DROP, EPI_GELU_BWD, EPI_NONE = 0, 1, 2, 3, 4
+
+
+def linear_nt(A, W, bias=None, *, pro=PRO_NONE, ln=None, pro_seed=0, pro_p=0.0, epi=EPI_BIAS,
+              res=None, aux=None, epi_seed=0, epi_p=0.0, out=None):
+    """C[M,N] = pro(A)[M,K] . W[N,K]^T with fused epilogue (see include/hwgat_hip.h).
+    Returns C, or (C, C2) for EPI_BIAS_GELU_DROP (C2 = pre-activation)."""
+    K = A.shape[-1]
+    M = A.numel() // K
+    N = W.shape[0]
+    C = out if out is not None else torch.empty(*A.shape[:-1], N, device=A.device, dtype=torch.float32)
+    C2 = torch.empty_like(C) if epi == EPI_BIAS_GELU_DROP else None
+    mean = rstd = gamma = beta = None
+    if pro == PRO_LN:
+        mean, rstd, gamma, beta = ln
+    call("hwgat_linear_nt_f32", ptr(A), ptr(W), ptr(bias), ptr(C), M, N, K, pro, ptr(mean), ptr(rstd),
+         ptr(gamma), ptr(beta), pro_seed & 0xFFFFFFFF, float(pro_p), epi, ptr(res), ptr(C2), ptr(aux),
+         epi_seed & 0xFFFFFFFF, float(epi_p), stream())
+    return (C, C2) if C2 is not None else C
+
+
+def linear_tn(A, Bm, dW, db=None, *, pro_seed=0, pro_p=0.0, ln=None):
+    """dW[N,K] += dropmask(A)[M,N]^T . ln(Bm)[M,K]; db[N] += colsum(dropmask(A)).
+    ln = (mean, rstd, gamma, beta) normalises Bm on the fly."""
+    N, K = dW.shape
+    M = A.numel() // N
+    mean, rstd, gamma, beta = ln if ln is not None else (None, None, None, None)
+    call("hwgat_linear_tn_f32", ptr(A), ptr(Bm), ptr(dW), ptr(db), M, N, K, pro_seed & 0xFFFFFFFF,
+         float(pro_p), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), stream())
+
+
+def ln_stats(x, gamma, beta):
+    """per-row mean / rstd only (consumers normalise on the fly)"""
+    d = x.shape[-1]
+    n = x.numel() // d
+    mean = torch.empty(n, device=x.device, dtype=torch.float32)
+    rstd = torch.empty_like(mean)
+    call("hwgat_ln_fwd", ptr(x), ptr(gamma), ptr(beta), None, ptr(mean), ptr(rstd), n, d, dtype_code(x), stream())
+    return mean, rstd
+
+
+def ln_backward(dy, x, mean, rstd, gamma, dres, dgamma, dbeta):
+    """dx = dLN(dy) (+ dres); dgamma/dbeta accumulated in place"""
+    d = x.shape[-1]
+    dx = torch.empty_like(x)
+    call("hwgat_ln_bwd", ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(dres), ptr(dx),
+         ptr(dgamma), ptr(dbeta), x.numel() // d, d, dtype_code(x), stream())
+    return dx
+
+
+def transpose(W):
+    R, C = W.shape
+    out = torch.empty(C, R, device=W.device, dtype=torch.float32)
+    call("hwgat_transpose_f32", ptr(W), ptr(out), R, C, stream())
+    return out
+
+
+def dropout_mask(shape, seed, p, device):
+    out = torch.empty(shape, device=device, dtype=torch.float32)
+    call("hwgat_dropout_mask_f32", ptr(out), out.numel(), seed & 0xFFFFFFFF, float(p), stream())
+    return out

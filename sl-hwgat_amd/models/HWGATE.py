@@ -21,6 +21,7 @@ from torch import nn
 import torch.nn.functional as tF
 
 from .. import functional as HF
+from ..block import fused_block
 
 _SUPPORTED_WIDTHS = (128, 256, 512, 1024)
 
@@ -120,6 +121,8 @@ class Model(nn.Module):
         self.part_index: Optional[torch.Tensor] = None           # set by use_part_table()
         self.activation_dtype = torch.float32
         self.threshold_override: Optional[List[float]] = None    # tests: inject train thresholds
+        self.fused_linears = True      # hand-written f32 MFMA linears with fused LN/GELU/dropout/residual
+        self._drop_calls = 0
         if device is not None:
             self.to(device)
 
@@ -148,7 +151,15 @@ class Model(nn.Module):
             return tF.dropout(x, self.drop_rate, True)
         return x
 
-    def _block(self, h, blk, n_heads, shifted, thr):
+    def _seeds(self, k):
+        """three dropout-site seeds for block k of this forward call (host integers, no sync)"""
+        base = (torch.initial_seed() * 0x9E3779B1 + self._drop_calls * 0x85EBCA77) & 0xFFFFFFFF
+        return [(base + (k * 4 + s) * 0xC2B2AE35) & 0xFFFFFFFF for s in range(3)]
+
+    def _block(self, h, blk, n_heads, shifted, thr, k=0):
+        if self.fused_linears and h.dtype == torch.float32 and (h.numel() // h.shape[-1]) % 128 == 0:
+            p = self.drop_rate if self.training else 0.0
+            return fused_block(h.contiguous(), thr, blk, self._mask_bits, n_heads, shifted, p, self._seeds(k))
         xn = HF.layer_norm(h, blk.norm1.weight, blk.norm1.bias)
         qkv = self._linear(xn, blk.attn.qkv)
         o = HF.window_attention(qkv, self._mask_bits, thr, n_heads, shifted)
@@ -171,6 +182,8 @@ class Model(nn.Module):
         if self.pe:
             h = self._drop(h)
         k = 0
+        if self.training:
+            self._drop_calls += 1
         for i, stage in enumerate(self.layers):
             for j, blk in enumerate(stage.blocks):
                 thr = None
@@ -179,7 +192,7 @@ class Model(nn.Module):
                         thr = torch.full((1,), float(self.threshold_override[k]), device=x.device)
                     else:
                         thr = torch.rand(1, device=x.device)      # device RNG, no host sync
-                h = self._block(h, blk, self.num_heads[i], j % 2 == 1, thr)
+                h = self._block(h, blk, self.num_heads[i], j % 2 == 1, thr, k)
                 k += 1
             if i < self.num_layers - 1:
                 h = HF.temporal_merge(h)

@@ -1,0 +1,103 @@
+"""GPU parity of the hand-written fp32 MFMA linear kernels vs fp64 torch on the CPU."""
+import importlib
+
+import pytest
+import torch
+
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+hw = importlib.import_module("sl-hwgat_amd")
+HF = hw.functional
+DEV = "cuda:0"
+TOL = 2e-5
+
+
+def _data(M, N, K, seed):
+    g = torch.Generator().manual_seed(seed)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) * 0.1
+    b = torch.randn(N, generator=g)
+    return A, W, b
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (384, 256, 128), (1280, 384, 128), (2176, 128, 256), (1152, 512, 512)])
+def test_nt_plain_and_bias(M, N, K):
+    A, W, b = _data(M, N, K, M + N)
+    ref = A.double() @ W.double().t()
+    got = HF.linear_nt(A.to(DEV), W.to(DEV), None, epi=HF.EPI_NONE)
+    assert rel_err(got.cpu(), ref) < TOL
+    got = HF.linear_nt(A.to(DEV), W.to(DEV), b.to(DEV), epi=HF.EPI_BIAS)
+    assert rel_err(got.cpu(), ref + b.double()) < TOL
+    # persistent path: more tiles than resident blocks
+    if M == 1280:
+        A2 = torch.randn(128 * 700, K, generator=torch.Generator().manual_seed(1))
+        got = HF.linear_nt(A2.to(DEV), W.to(DEV), b.to(DEV))
+        assert rel_err(got.cpu(), A2.double() @ W.double().t() + b.double()) < TOL
+
+
+def test_nt_layernorm_prologue():
+    M, N, K = 640, 384, 128
+    A, W, b = _data(M, N, K, 3)
+    g = torch.Generator().manual_seed(9)
+    gamma, beta = torch.randn(K, generator=g), torch.randn(K, generator=g)
+    Ad = A.to(DEV)
+    y = torch.empty_like(Ad)
+    mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    L = hw._lib
+    L.call("hwgat_ln_fwd", L.ptr(Ad), L.ptr(gamma.to(DEV)), L.ptr(beta.to(DEV)), L.ptr(y), L.ptr(mean), L.ptr(rstd),
+           M, K, 0, L.stream())
+    ref = torch.nn.functional.layer_norm(A.double(), (K,), gamma.double(), beta.double()) @ W.double().t() + b.double()
+    got = HF.linear_nt(Ad, W.to(DEV), b.to(DEV), pro=HF.PRO_LN, ln=(mean, rstd, gamma.to(DEV), beta.to(DEV)))
+    assert rel_err(got.cpu(), ref) < TOL
+
+
+@pytest.mark.parametrize("p", [0.0, 0.1, 0.5])
+def test_nt_dropout_residual_gelu_epilogues(p):
+    M, N, K = 512, 256, 128
+    A, W, b = _data(M, N, K, 5)
+    res = torch.randn(M, N, generator=torch.Generator().manual_seed(2))
+    Ad, Wd, bd = A.to(DEV), W.to(DEV), b.to(DEV)
+    mask = HF.dropout_mask((M, N), 1234, p, DEV).cpu().double()
+    keep = (mask != 0).double().mean().item()
+    assert abs(keep - (1 - p)) < 0.01 and (p == 0 or abs(mask.max().item() - 1 / (1 - p)) < 1e-6)
+    lin = A.double() @ W.double().t() + b.double()
+    got = HF.linear_nt(Ad, Wd, bd, epi=HF.EPI_BIAS_DROP_RES, res=res.to(DEV), epi_seed=1234, epi_p=p)
+    assert rel_err(got.cpu(), res.double() + lin * mask) < TOL
+    u, h1 = HF.linear_nt(Ad, Wd, bd, epi=HF.EPI_BIAS_GELU_DROP, epi_seed=1234, epi_p=p)
+    assert rel_err(h1.cpu(), lin) < TOL
+    assert rel_err(u.cpu(), torch.nn.functional.gelu(lin) * mask) < TOL
+    # backward epilogue: d_h1 = (dy . W) * mask * gelu'(h1)
+    dy = torch.randn(M, K, generator=torch.Generator().manual_seed(4))      # here "A" plays dY [M,K'] and W [N,K']
+    h1r = lin.clone().requires_grad_(True)
+    torch.nn.functional.gelu(h1r).sum().backward()
+    ref = (dy.double() @ W.double().t()) * mask * h1r.grad
+    got = HF.linear_nt(dy.to(DEV), Wd, None, epi=HF.EPI_GELU_BWD, aux=h1, epi_seed=1234, epi_p=p)
+    assert rel_err(got.cpu(), ref) < 5e-5
+    # dropout prologue on A (mask indexed over A's own [M,K] elements)
+    maskA = HF.dropout_mask((M, K), 77, p, DEV).cpu().double()
+    got = HF.linear_nt(Ad, Wd, None, pro=HF.PRO_DROP, pro_seed=77, pro_p=p, epi=HF.EPI_NONE)
+    assert rel_err(got.cpu(), (A.double() * maskA) @ W.double().t()) < TOL
+
+
+@pytest.mark.parametrize("M,N,K,p", [(256, 128, 128, 0.0), (4096, 384, 128, 0.0), (32 * 301, 256, 512, 0.1), (65536, 128, 256, 0.0)])
+def test_tn_weight_and_bias_grad(M, N, K, p):
+    g = torch.Generator().manual_seed(M + K)
+    dY, X = torch.randn(M, N, generator=g), torch.randn(M, K, generator=g)
+    mask = HF.dropout_mask((M, N), 5, p, DEV).cpu().double() if p > 0 else torch.ones(M, N, dtype=torch.float64)
+    dW = torch.zeros(N, K, device=DEV)
+    db = torch.zeros(N, device=DEV)
+    HF.linear_tn(dY.to(DEV), X.to(DEV), dW, db, pro_seed=5, pro_p=p)
+    ref = (dY.double() * mask).t() @ X.double()
+    assert rel_err(dW.cpu(), ref) < TOL
+    assert rel_err(db.cpu(), (dY.double() * mask).sum(0)) < TOL
+    # accumulates into existing contents
+    HF.linear_tn(dY.to(DEV), X.to(DEV), dW, None, pro_seed=5, pro_p=p)
+    assert rel_err(dW.cpu(), 2 * ref) < TOL
+
+
+def test_transpose():
+    W = torch.randn(384, 128)
+    assert torch.equal(HF.transpose(W.to(DEV)).cpu(), W.t().contiguous())
+    W = torch.randn(100, 37)
+    assert torch.equal(HF.transpose(W.to(DEV)).cpu(), W.t().contiguous())

@@ -15,6 +15,17 @@ DEV = torch.device("cuda:0")
 TOL = 1e-3            # north_star: 1e-3 relative fp32; observed far below
 
 
+@pytest.fixture(params=[True, False], ids=["fused", "libgemm"], autouse=True)
+def fused_mode(request):
+    """every model test runs with the hand-written fused linears and with the v1 (library GEMM) path"""
+    global FUSED
+    FUSED = request.param
+    yield
+
+
+FUSED = True
+
+
 def build(fx, drop=0.0):
     cfg, seed, _ = cfg_of(fx)
     hp = hw.HWGATEParams({"src_len": cfg["temporal_dim"], "num_class": cfg["num_classes"]}, cfg["kp_dim"],
@@ -24,6 +35,7 @@ def build(fx, drop=0.0):
     wstd = float(fx["wstd"]) if "wstd" in fx else 0.08
     res = model.load_state_dict(O.synth_params(seed, weight_std=wstd, **cfg), strict=False)
     assert not res.unexpected_keys and all(k.endswith("attn_mask") for k in res.missing_keys)
+    model.fused_linears = FUSED
     return model.to(DEV), cfg
 
 
@@ -40,8 +52,8 @@ def test_eval_logits_and_block_taps_cfg1():
     orig = model._block
     counter = {"k": 0}
 
-    def tapped(h, blk, n_heads, shifted, thr):
-        out = orig(h, blk, n_heads, shifted, thr)
+    def tapped(h, blk, n_heads, shifted, thr, k=0):
+        out = orig(h, blk, n_heads, shifted, thr, k)
         taps[f"block{counter['k']}"] = out.detach()
         counter["k"] += 1
         return out
@@ -118,6 +130,7 @@ def test_fresh_inputs_vs_oracle_and_raw_joint_path():
     hp.drop_rate = 0.0
     model = hw.Model(*hp.get_model_params())
     model.load_state_dict(params, strict=False)
+    model.fused_linears = FUSED
     idx = hw.part_table(27, nW)
     model.use_part_table(idx).eval()
     g = torch.Generator().manual_seed(2)
@@ -150,3 +163,44 @@ def test_dropout_train_mode_runs_and_is_stochastic():
     assert torch.isfinite(a).all() and not torch.equal(a, b)
     a.sum().backward()
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+
+
+def test_fused_dropout_matches_unfused_math_with_same_masks():
+    """train mode, drop 0.1: the fused block must equal a plain-torch evaluation that uses the
+    very masks the kernels generate (hwgat_dropout_mask_f32) -- forward and input gradient."""
+    torch.manual_seed(5)
+    B, F, K, d, nH, p = 2, 4, 32, 128, 2, 0.1
+    hp = hw.HWGATEParams({"src_len": 8, "num_class": 3}, 2, DEV, num_kps=K)
+    model = hw.Model(*hp.get_model_params()).to(DEV)
+    blk = model.layers[0].blocks[1]
+    for prm in blk.parameters():
+        prm.data.normal_(0, 0.1)
+    from importlib import import_module
+    fb = import_module("sl-hwgat_amd.block")
+    x = torch.randn(B, F, K, d, device=DEV, requires_grad=True)
+    seeds = [11, 22, 33]
+    thr = torch.tensor([0.2], device=DEV)
+    out = fb.fused_block(x, thr, blk, model._mask_bits, nH, True, p, seeds)
+    g = torch.randn_like(out)
+    out.backward(g)
+    gx = x.grad.clone()
+    grads = {n: q.grad.clone() for n, q in blk.named_parameters()}
+    for q in blk.parameters():
+        q.grad = None
+    # reference evaluation with torch ops + the same masks
+    HF = hw.functional
+    xr = x.detach().clone().requires_grad_(True)
+    m1 = HF.dropout_mask((B, F, K, d), seeds[0], p, DEV)
+    m2 = HF.dropout_mask((B, F, K, 2 * d), seeds[1], p, DEV)
+    m3 = HF.dropout_mask((B, F, K, d), seeds[2], p, DEV)
+    tF = torch.nn.functional
+    xn = tF.layer_norm(xr, (d,), blk.norm1.weight, blk.norm1.bias)
+    o = HF.window_attention(tF.linear(xn, blk.attn.qkv.weight, blk.attn.qkv.bias), model._mask_bits, thr, nH, True)
+    y = xr + tF.linear(o, blk.attn.proj.weight, blk.attn.proj.bias) * m1
+    u = tF.gelu(tF.linear(tF.layer_norm(y, (d,), blk.norm2.weight, blk.norm2.bias), blk.ff.fc1.weight, blk.ff.fc1.bias)) * m2
+    ref = y + tF.linear(u, blk.ff.fc2.weight, blk.ff.fc2.bias) * m3
+    ref.backward(g)
+    assert rel_err(out.detach().cpu(), ref.detach().cpu()) < 1e-5
+    assert rel_err(gx.cpu(), xr.grad.cpu()) < 1e-4
+    for n, q in blk.named_parameters():
+        assert rel_err(grads[n].cpu(), q.grad.cpu()) < 1e-4, n
