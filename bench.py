@@ -152,6 +152,16 @@ def main():
                               "unit": "GB/s", "frac": round(ach / HBM_PEAK, 4), "traffic": None,
                               "launches": n, "avg_us": round(avg * 1e6, 1),
                               "bytes_per_launch": attn_bytes(E, itemsize, bwd)}
+        # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 correction + WRITE_SIZE,
+        # separate passes; profiles/r01_attn_pmc_traffic.json) -- only valid for the shape they were taken on
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_attn_pmc_traffic.json")) as fh:
+                pmc = json.load(fh)
+            if pmc["E_bytes"] == E * itemsize and args.dtype == "f32":
+                for name in kern:
+                    kern[name]["traffic"] = pmc[name]["traffic_bytes_per_launch"]
+        except (OSError, KeyError):
+            pass
         others = {k: {"launches": v[0], "total_ms": round(v[1], 3)} for k, v in timers.items()
                   if k not in kern}
         hip_ms = sum(v[1] for v in timers.values())

@@ -40,19 +40,33 @@ struct NtArgs {
     uint32_t pro_seed, epi_seed; float pro_p, epi_p;
 };
 
-// keep iff hash >= p * 2^32; survivors are scaled by 1/(1-p)
-__device__ __forceinline__ uint32_t mix32(uint32_t seed, uint64_t idx) {
-    uint32_t x = (uint32_t)idx * 747796405u + (uint32_t)(idx >> 32) * 2891336453u + seed;
-    x = ((x >> ((x >> 28) + 4u)) ^ x) * 277803737u;
-    x ^= x >> 22;
-    x *= 2654435761u;
+// Dropout mask: a counter-based hash of (seed, element index).  One 32-bit hash serves an
+// aligned PAIR of elements (16 bits each): keep iff its 16 bits >= p * 65536 (p is thereby
+// quantised to 1/65536); survivors are scaled by 1/(1-p).
+__device__ __forceinline__ uint32_t mix32(uint32_t seed, uint64_t pair) {
+    uint32_t x = ((uint32_t)pair ^ seed) * 0x9E3779B1u + (uint32_t)(pair >> 32) * 0x85EBCA77u;
+    x ^= x >> 15;
+    x *= 0x2C1B3C6Du;
+    x ^= x >> 12;
+    x *= 0x297A2D39u;
     return x ^ (x >> 15);
 }
 __device__ __forceinline__ float drop_keep(uint32_t seed, uint64_t idx, uint32_t thresh, float scale) {
-    return mix32(seed, idx) >= thresh ? scale : 0.f;
+    const uint32_t h = mix32(seed, idx >> 1);
+    return ((idx & 1 ? h >> 16 : h & 0xffffu) >= thresh) ? scale : 0.f;
+}
+// four consecutive elements starting at an index that is a multiple of 4
+__device__ __forceinline__ f32x4 drop_keep4(uint32_t seed, uint64_t idx, uint32_t thresh, float scale) {
+    const uint32_t h0 = mix32(seed, idx >> 1), h1 = mix32(seed, (idx >> 1) + 1);
+    f32x4 k;
+    k.x = (h0 & 0xffffu) >= thresh ? scale : 0.f;
+    k.y = (h0 >> 16) >= thresh ? scale : 0.f;
+    k.z = (h1 & 0xffffu) >= thresh ? scale : 0.f;
+    k.w = (h1 >> 16) >= thresh ? scale : 0.f;
+    return k;
 }
 __device__ __forceinline__ uint32_t drop_thresh(float p) {
-    return p <= 0.f ? 0u : (uint32_t)fminf(p * 4294967296.0f, 4294967040.0f);
+    return p <= 0.f ? 0u : (uint32_t)fminf(p * 65536.0f + 0.5f, 65535.0f);
 }
 
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
@@ -70,7 +84,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_k(NtArgs p) {
     const int lq = lane & 31, hh = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
     const int tiles_n = p.N / BN;
-    const int64_t n_tiles = (p.M / BM) * tiles_n;
+    const int n_tiles = (int)(p.M / BM) * tiles_n;
     const int n_slab = p.K / BK;
     const int lrow = tid >> 3, lc4 = (tid & 7) * 4;          // this thread stages rows lrow+32*i, floats lc4..lc4+3
     const uint32_t pro_th = drop_thresh(p.pro_p);
@@ -81,19 +95,19 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_k(NtArgs p) {
 
     // XCD-aware tile order: blocks b, b+8, b+16, ... share an XCD (and its L2); give them the
     // n-tiles of ONE 128-row block of A, so A streams from HBM once and is re-read from L2.
-    const int64_t row_blocks = p.M / BM;
-    const int64_t swz_tiles = (row_blocks / 8) * 8 * tiles_n;
-    auto tile_origin = [&](int64_t t, int64_t& m0, int& n0) {
-        int64_t rb; int nt;
+    const int row_blocks = (int)(p.M / BM);
+    const int swz_tiles = (row_blocks / 8) * 8 * tiles_n;
+    auto tile_origin = [&](int t, int64_t& m0, int& n0) {
+        int rb, nt;
         if (t < swz_tiles) {
             rb = (t / (8 * tiles_n)) * 8 + (t & 7);
-            nt = (int)((t >> 3) % tiles_n);
+            nt = (t >> 3) % tiles_n;
         } else {
-            const int64_t w = t - swz_tiles;
+            const int w = t - swz_tiles;
             rb = (row_blocks / 8) * 8 + w / tiles_n;
-            nt = (int)(w % tiles_n);
+            nt = w % tiles_n;
         }
-        m0 = rb * BM;
+        m0 = (int64_t)rb * BM;
         n0 = nt * BN;
     };
     auto issue = [&](int64_t m0, int n0, int slab, bool new_tile) {
@@ -126,20 +140,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_k(NtArgs p) {
                 a.z = (a.z - ln_mean[i]) * ln_rstd[i] * g.z + b.z;
                 a.w = (a.w - ln_mean[i]) * ln_rstd[i] * g.w + b.w;
             } else if constexpr (PRO == PRO_DROP) {
-                if (pro_th) {
-                    const uint64_t e = (uint64_t)(m0 + lrow + 32 * i) * p.K + k0;
-                    a.x *= drop_keep(p.pro_seed, e, pro_th, pro_sc);
-                    a.y *= drop_keep(p.pro_seed, e + 1, pro_th, pro_sc);
-                    a.z *= drop_keep(p.pro_seed, e + 2, pro_th, pro_sc);
-                    a.w *= drop_keep(p.pro_seed, e + 3, pro_th, pro_sc);
-                }
+                if (pro_th) a *= drop_keep4(p.pro_seed, (uint64_t)(m0 + lrow + 32 * i) * p.K + k0, pro_th, pro_sc);
             }
             *reinterpret_cast<f32x4*>(As + (lrow + 32 * i) * LDT + lc4) = a;
             *reinterpret_cast<f32x4*>(Ws + (lrow + 32 * i) * LDT + lc4) = rw[i];
         }
     };
 
-    int64_t t = blockIdx.x;
+    int t = blockIdx.x;
     if (t >= n_tiles) return;
     int64_t m0; int n0;
     tile_origin(t, m0, n0);
@@ -157,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_k(NtArgs p) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-        int64_t tn = t, mn = m0; int nn = n0;
+        int tn = t; int64_t mn = m0; int nn = n0;
         for (int s = 0; s < n_slab; ++s) {
             // prefetch the next slab (possibly the next tile's first) into registers
             bool have_next = true, new_tile = false;
@@ -222,12 +230,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_k(NtArgs p) {
                     f32x4 v = *reinterpret_cast<const f32x4*>(stg + rr * SLD + ec) + bv;
                     f32x4 dk = {1.f, 1.f, 1.f, 1.f};
                     if constexpr (EPI == EPI_BIAS_DROP_RES || EPI == EPI_BIAS_GELU_DROP || EPI == EPI_GELU_BWD) {
-                        if (epi_th) {
-                            dk.x = drop_keep(p.epi_seed, (uint64_t)off, epi_th, epi_sc);
-                            dk.y = drop_keep(p.epi_seed, (uint64_t)off + 1, epi_th, epi_sc);
-                            dk.z = drop_keep(p.epi_seed, (uint64_t)off + 2, epi_th, epi_sc);
-                            dk.w = drop_keep(p.epi_seed, (uint64_t)off + 3, epi_th, epi_sc);
-                        }
+                        if (epi_th) dk = drop_keep4(p.epi_seed, (uint64_t)off, epi_th, epi_sc);
                     }
                     if constexpr (EPI == EPI_BIAS_DROP_RES) {
                         v = *reinterpret_cast<const f32x4*>(p.res + off) + v * dk;
@@ -311,13 +314,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_k(TnArgs p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             f32x4 a = ra[i], b = rb[i];
-            if constexpr (PRO == PRO_DROP) {
-                const uint64_t e = (uint64_t)(r0 + 8 * i) * p.N + n0 + lc4;
-                a.x *= drop_keep(p.pro_seed, e, pro_th, pro_sc);
-                a.y *= drop_keep(p.pro_seed, e + 1, pro_th, pro_sc);
-                a.z *= drop_keep(p.pro_seed, e + 2, pro_th, pro_sc);
-                a.w *= drop_keep(p.pro_seed, e + 3, pro_th, pro_sc);
-            }
+            if constexpr (PRO == PRO_DROP)
+                a *= drop_keep4(p.pro_seed, (uint64_t)(r0 + 8 * i) * p.N + n0 + lc4, pro_th, pro_sc);
             if constexpr (BLN) b = (b - bm[i]) * bs[i] * lg + lb;
             colsum += a;
             *reinterpret_cast<f32x4*>(As + (lrow + 8 * i) * 128 + lc4) = a;
@@ -342,15 +340,32 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_k(TnArgs p) {
         if (have_next) issue(it + 1);
         const float* As = sm + buf * (2 * TM * 128) + wn * 64 + lq;
         const float* Bs = sm + buf * (2 * TM * 128) + TM * 128 + wk * 64 + lq;
+        // software-pipelined operand fetch: the LDS reads of chunk c+1 are in flight while the
+        // 16 MFMAs of chunk c issue (the compiler then waits with counted lgkmcnt, not 0)
+        constexpr int CH = 4, NCH = TM / 2 / CH;
+        float fa0[2][CH], fa1[2][CH], fb0[2][CH], fb1[2][CH];
+        auto fetch = [&](int c, int slot) {
 #pragma unroll
-        for (int s = 0; s < TM / 2; ++s) {
-            const int ro = (2 * s + hh) * 128;
-            const float a0 = As[ro], a1 = As[ro + 32];
-            const float b0 = Bs[ro], b1 = Bs[ro + 32];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            for (int e = 0; e < CH; ++e) {
+                const int ro = (2 * (c * CH + e) + hh) * 128;
+                fa0[slot][e] = As[ro]; fa1[slot][e] = As[ro + 32];
+                fb0[slot][e] = Bs[ro]; fb1[slot][e] = Bs[ro + 32];
+            }
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            if (c + 1 < NCH) fetch(c + 1, (c + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);          // keep the prefetch above this chunk's MFMAs
+#pragma unroll
+            for (int e = 0; e < CH; ++e) {
+                const float a0 = fa0[c & 1][e], a1 = fa1[c & 1][e], b0 = fb0[c & 1][e], b1 = fb1[c & 1][e];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (have_next) commit(buf ^ 1, it + 1);
         __syncthreads();
@@ -413,7 +428,7 @@ extern "C" int hwgat_linear_nt_f32(const float* A, const float* W, const float* 
                                    int epi, const float* res, float* C2, const float* aux, uint32_t epi_seed,
                                    float epi_p, void* stream) {
     if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) return HWGAT_EINVAL;
-    if (M % BM || N % BN || K % BK) return HWGAT_ESHAPE;
+    if (M % BM || N % BN || K % BK || (M / BM) * (int64_t)(N / BN) > 0x7fffffff) return HWGAT_ESHAPE;
     if (pro == PRO_LN && (!mean || !rstd || !gamma || !beta)) return HWGAT_EINVAL;
     if (epi == EPI_BIAS_DROP_RES && !res) return HWGAT_EINVAL;
     if (epi == EPI_BIAS_GELU_DROP && !C2) return HWGAT_EINVAL;
@@ -439,9 +454,15 @@ extern "C" int hwgat_linear_tn_f32(const float* A, const float* B, float* dW, fl
     if (M % TM || N % 128 || K % 128) return HWGAT_ESHAPE;
     if (pro_p < 0.f || pro_p >= 1.f) return HWGAT_EINVAL;
     const int n_tiles = (N / 128) * (K / 128);
-    // aim at ~4 blocks per CU over the chip; each split at least 8 LDS stages deep
-    int64_t want = (1024 + n_tiles - 1) / n_tiles;
-    const int64_t max_split = M / (TM * 8) > 0 ? M / (TM * 8) : 1;
+    // Blocks are equal-sized and 2 are resident per CU (512 slots), so they execute in rounds:
+    // pick the number of M slices so that blocks = n_split * n_tiles is an exact multiple of 512
+    // (no nearly-empty last round), about 2-3 rounds, and every slice is >= 16 LDS stages deep.
+    auto gcd = [](int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; };
+    const int r_min = n_tiles / gcd(n_tiles, 512);
+    int r = r_min;
+    while (r < 2) r += r_min;
+    int64_t want = (int64_t)512 * r / n_tiles;
+    const int64_t max_split = M / (TM * 16) > 0 ? M / (TM * 16) : 1;
     if (want > max_split) want = max_split;
     if (want < 1) want = 1;
     int64_t rows = (M + want - 1) / want;

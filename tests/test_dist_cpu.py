@@ -1,0 +1,89 @@
+"""CPU, world_size 2 over gloo: the bucketed gradient exchange used for the N>1 path.
+
+The GradReducer is model-agnostic, so it is exercised here with the oracle model (allowed in
+tests/): two ranks each take half of a global batch; after `finish()` every rank must hold the
+gradient of the mean loss over the GLOBAL batch, identical to a single-process run."""
+import importlib
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _make(seed=4):
+    from oracle import hwgat_oracle as O
+    cfg = dict(kp_dim=2, temporal_dim=8, num_classes=5, embed_dim=128, num_kps=32)
+    params = O.synth_params(seed, **cfg)
+    plist = {k: torch.nn.Parameter(v.clone(), requires_grad=k not in ("B", "pos_encoder.pe")) for k, v in params.items()}
+    model = O.OracleHWGAT(plist, num_kps=32, temporal_dim=8)
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(4, 8, 32, 2, generator=g)
+    y = torch.randint(0, 5, (4,), generator=g)
+    return O, model, plist, x, y
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    dmod = importlib.import_module("sl-hwgat_amd.dist")
+    O, model, plist, x, y = _make()
+    if rank != 0:                                   # ranks start different; broadcast must fix it
+        for p in plist.values():
+            p.data.add_(1.0)
+    dmod.broadcast_parameters(torch.nn.ParameterList(plist.values()))
+    trainable = [p for p in plist.values() if p.requires_grad]
+    red = dmod.GradReducer(trainable, bucket_bytes=1 << 20)
+    assert len(red.buckets) > 3                     # several buckets -> overlap path exercised
+    for step in range(2):                           # second step checks zero_grad/bucket reuse
+        red.zero_grad()
+        xs, ys = x[rank * 2:(rank + 1) * 2], y[rank * 2:(rank + 1) * 2]
+        O.smoothed_cross_entropy(model.forward(xs), ys).backward()
+        red.finish()
+    torch.save({k: p.grad.clone() for k, p in plist.items() if p.grad is not None},
+               os.path.join(out_dir, f"grads{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_bucketed_allreduce_matches_single_process(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    O, model, plist, x, y = _make()
+    O.smoothed_cross_entropy(model.forward(x), y).backward()
+    g0 = torch.load(os.path.join(tmp_path, "grads0.pt"))
+    g1 = torch.load(os.path.join(tmp_path, "grads1.pt"))
+    assert set(g0) == {k for k, p in plist.items() if p.grad is not None}
+    for k, p in plist.items():
+        if p.grad is None:
+            continue
+        assert torch.equal(g0[k], g1[k]), k                      # ranks agree bit for bit
+        err = (g0[k] - p.grad).norm() / p.grad.norm().clamp_min(1e-12)
+        assert err < 1e-5, (k, err)                              # == gradient of the global-batch mean loss
+
+
+def test_single_process_reducer_is_a_noop_wrapper():
+    dmod = importlib.import_module("sl-hwgat_amd.dist")
+    lin = torch.nn.Linear(8, 4)
+    red = dmod.GradReducer(lin.parameters(), bucket_bytes=64)
+    red.zero_grad()
+    lin(torch.ones(2, 8)).sum().backward()
+    red.finish()
+    assert torch.allclose(lin.weight.grad, torch.full((4, 8), 2.0))
+    assert lin.weight.grad.data_ptr() >= red.buckets[-1]["flat"].data_ptr() or len(red.buckets) > 1
+    red.zero_grad()
+    assert float(lin.weight.grad.abs().sum()) == 0.0
