@@ -24,16 +24,18 @@ class _FusedBlock(torch.autograd.Function):
     def forward(ctx, x, thr, n1w, n1b, wqkv, bqkv, wp, bp, n2w, n2b, w1, b1, w2, b2, cfg):
         bits, n_heads, shifted, p, seeds = cfg
         B, F, K, d = x.shape
+        dt = x.dtype                              # fp32, or bf16 activations with fp32 master weights
+        cw = (lambda w: w) if dt == torch.float32 else (lambda w: w.to(dt))
         m1, r1 = HF.ln_stats(x, n1w, n1b)
-        qkv = HF.linear_nt(x, wqkv, bqkv, pro=HF.PRO_LN, ln=(m1, r1, n1w, n1b))
+        qkv = HF.linear_nt(x, cw(wqkv), bqkv, pro=HF.PRO_LN, ln=(m1, r1, n1w, n1b))
         o = torch.empty_like(x)
         HF.call("hwgat_win_attn_fwd", HF.ptr(qkv), HF.ptr(o), HF.ptr(bits), HF.ptr(thr), B, F, K // 16, n_heads,
-                d // n_heads, int(shifted), 0, HF.stream())
-        y = HF.linear_nt(o, wp, bp, epi=HF.EPI_BIAS_DROP_RES, res=x, epi_seed=seeds[0], epi_p=p)
+                d // n_heads, int(shifted), HF.dtype_code(x), HF.stream())
+        y = HF.linear_nt(o, cw(wp), bp, epi=HF.EPI_BIAS_DROP_RES, res=x, epi_seed=seeds[0], epi_p=p)
         m2, r2 = HF.ln_stats(y, n2w, n2b)
-        u, h1 = HF.linear_nt(y, w1, b1, pro=HF.PRO_LN, ln=(m2, r2, n2w, n2b), epi=HF.EPI_BIAS_GELU_DROP,
+        u, h1 = HF.linear_nt(y, cw(w1), b1, pro=HF.PRO_LN, ln=(m2, r2, n2w, n2b), epi=HF.EPI_BIAS_GELU_DROP,
                              epi_seed=seeds[1], epi_p=p)
-        out = HF.linear_nt(u, w2, b2, epi=HF.EPI_BIAS_DROP_RES, res=y, epi_seed=seeds[2], epi_p=p)
+        out = HF.linear_nt(u, cw(w2), b2, epi=HF.EPI_BIAS_DROP_RES, res=y, epi_seed=seeds[2], epi_p=p)
         ctx.save_for_backward(x, thr, n1w, n1b, wqkv, wp, n2w, n2b, w1, w2, m1, r1, qkv, o, y, m2, r2, h1, u)
         ctx.cfg = cfg
         return out
@@ -43,6 +45,7 @@ class _FusedBlock(torch.autograd.Function):
         x, thr, n1w, n1b, wqkv, wp, n2w, n2b, w1, w2, m1, r1, qkv, o, y, m2, r2, h1, u = ctx.saved_tensors
         bits, n_heads, shifted, p, seeds = ctx.cfg
         B, F, K, d = x.shape
+        dt = x.dtype
         dout = dout.contiguous()
         z = lambda t: torch.zeros_like(t)
         dn1w, dn1b, dn2w, dn2b = z(n1w), z(n1b), z(n2w), z(n2b)
@@ -53,21 +56,21 @@ class _FusedBlock(torch.autograd.Function):
 
         # ---- FFN branch: out = y + drop3(u W2^T + b2), u = drop2(gelu(h1)), h1 = LN2(y) W1^T + b1
         HF.linear_tn(dout, u, dw2, db2, pro_seed=seeds[2], pro_p=p)
-        d_h1 = HF.linear_nt(dout, HF.transpose(w2), None, pro=HF.PRO_DROP, pro_seed=seeds[2], pro_p=p,
+        d_h1 = HF.linear_nt(dout, HF.transpose(w2, dt), None, pro=HF.PRO_DROP, pro_seed=seeds[2], pro_p=p,
                             epi=HF.EPI_GELU_BWD, aux=h1, epi_seed=seeds[1], epi_p=p)
         HF.linear_tn(d_h1, y, dw1, db1, ln=(m2, r2, n2w, n2b))
-        d_z = HF.linear_nt(d_h1, HF.transpose(w1), None, epi=HF.EPI_NONE)
+        d_z = HF.linear_nt(d_h1, HF.transpose(w1, dt), None, epi=HF.EPI_NONE)
         del d_h1
         d_y = HF.ln_backward(d_z, y, m2, r2, n2w, dout, dn2w, dn2b)          # + shortcut gradient
         # ---- attention branch: y = x + drop1(o Wp^T + bp)
         HF.linear_tn(d_y, o, dwp, dbp, pro_seed=seeds[0], pro_p=p)
-        d_o = HF.linear_nt(d_y, HF.transpose(wp), None, pro=HF.PRO_DROP, pro_seed=seeds[0], pro_p=p,
+        d_o = HF.linear_nt(d_y, HF.transpose(wp, dt), None, pro=HF.PRO_DROP, pro_seed=seeds[0], pro_p=p,
                            epi=HF.EPI_NONE, out=d_z)
         dqkv = torch.empty_like(qkv)
         HF.call("hwgat_win_attn_bwd", HF.ptr(qkv), HF.ptr(d_o), HF.ptr(dqkv), HF.ptr(bits), HF.ptr(thr), B, F,
-                K // 16, n_heads, d // n_heads, int(shifted), 0, HF.stream())
+                K // 16, n_heads, d // n_heads, int(shifted), HF.dtype_code(x), HF.stream())
         HF.linear_tn(dqkv, x, dwqkv, dbqkv, ln=(m1, r1, n1w, n1b))
-        d_xn = HF.linear_nt(dqkv, HF.transpose(wqkv), None, epi=HF.EPI_NONE, out=d_o)
+        d_xn = HF.linear_nt(dqkv, HF.transpose(wqkv, dt), None, epi=HF.EPI_NONE, out=d_o)
         dx = HF.ln_backward(d_xn, x, m1, r1, n1w, d_y, dn1w, dn1b)
         return (dx, None, dn1w, dn1b, dwqkv, dbqkv, dwp, dbp, dn2w, dn2b, dw1, db1, dw2, db2, None)
 

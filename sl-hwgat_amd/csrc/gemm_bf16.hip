@@ -1,0 +1,461 @@
+// bf16 Linear-layer GEMMs for HWGAT on gfx950 (BASELINE config 3: bf16 activations with
+// MFMA projections), on v_mfma_f32_32x32x16_bf16 (fp32 accumulate) with the same fused
+// prologues / epilogues as the fp32 family (gemm_f32.hip).
+//
+// With bf16 MFMA (16x the fp32 rate) these kernels are HBM/L2-streaming kernels, not
+// compute kernels: the tile loop is organised for bytes in flight, the MFMAs are noise.
+//
+//  gemm_nt_bf16_k  C[M,N] = pro(A)[M,K] . W[N,K]^T (+epilogue); A, W, C bf16, bias/LN fp32.
+//                  128x128 tile, K slabs of 64 (one 128-byte line per row) double-buffered in LDS
+//                  with 144-byte rows (conflict-free ds_read_b128 operand fragments: a lane's
+//                  fragment is 8 consecutive k of its row, exactly one 16-byte read).
+//  gemm_tn_bf16_k  dW[N,K](fp32) += A[M,N]^T . B[M,K], db += colsum(A); A, B bf16.  The MFMA
+//                  operand needs 8 consecutive m per lane for a fixed column, i.e. a transposed
+//                  read of the row-major tile: ds_read_b64_tr_b16 (gfx950 hardware transpose)
+//                  on LDS rows padded to 320 bytes (4 rows of a 4x16 block land in disjoint
+//                  bank quarters -> conflict-free).
+#include "common.h"
+#include "fused_ops.h"
+
+namespace {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+__device__ __forceinline__ void unpack8(u32x4 r, float (&v)[8]) {
+    v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+    v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+    v[4] = __uint_as_float(r.z << 16); v[5] = __uint_as_float(r.z & 0xffff0000u);
+    v[6] = __uint_as_float(r.w << 16); v[7] = __uint_as_float(r.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+    bf16x2 t = {(bf16_t)a, (bf16_t)b};
+    return *reinterpret_cast<uint32_t*>(&t);
+}
+__device__ __forceinline__ u32x4 pack8(const float (&v)[8]) {
+    u32x4 r = {pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+    return r;
+}
+
+struct NtArgsB {
+    const bf16_t* A; const bf16_t* W; const float* bias; bf16_t* C;
+    bf16_t* C2; const bf16_t* res; const bf16_t* aux;
+    const float* mean; const float* rstd; const float* gamma; const float* beta;
+    int64_t M; int N, K;
+    uint32_t pro_seed, epi_seed; float pro_p, epi_p;
+};
+
+constexpr int BM = 128, BN = 128, BK = 64, LDT = BK + 8;       // LDS row stride in bf16 elements (144 B)
+
+template <int PRO, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_nt_bf16_k(NtArgsB p) {
+    __shared__ __attribute__((aligned(16))) bf16_t sm[2 * 2 * BM * LDT];      // [buf][A|W][128][72]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane & 31, hh = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = p.N / BN;
+    const int n_tiles = (int)(p.M / BM) * tiles_n;
+    const int n_slab = p.K / BK;
+    const int lrow = tid >> 3, lc8 = (tid & 7) * 8;            // rows lrow + 32*i, bf16 columns lc8..lc8+7
+    const uint32_t pro_th = drop_thresh(p.pro_p);
+    const float pro_sc = 1.0f / (1.0f - p.pro_p);
+
+    u32x4 ra[4], rw[4];
+    float ln_mean[4], ln_rstd[4];
+
+    const int row_blocks = (int)(p.M / BM);
+    const int swz_tiles = (row_blocks / 8) * 8 * tiles_n;
+    auto tile_origin = [&](int t, int64_t& m0, int& n0) {
+        int rb, nt;
+        if (t < swz_tiles) {
+            rb = (t / (8 * tiles_n)) * 8 + (t & 7);
+            nt = (t >> 3) % tiles_n;
+        } else {
+            const int w = t - swz_tiles;
+            rb = (row_blocks / 8) * 8 + w / tiles_n;
+            nt = w % tiles_n;
+        }
+        m0 = (int64_t)rb * BM;
+        n0 = nt * BN;
+    };
+    auto issue = [&](int64_t m0, int n0, int slab, bool new_tile) {
+        const int k0 = slab * BK + lc8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t row = m0 + lrow + 32 * i;
+            ra[i] = *reinterpret_cast<const u32x4*>(p.A + row * p.K + k0);
+            rw[i] = *reinterpret_cast<const u32x4*>(p.W + (int64_t)(n0 + lrow + 32 * i) * p.K + k0);
+            if constexpr (PRO == PRO_LN) {
+                if (new_tile) { ln_mean[i] = p.mean[row]; ln_rstd[i] = p.rstd[row]; }
+            }
+        }
+    };
+    auto commit = [&](int buf, int64_t m0, int slab) {
+        bf16_t* As = sm + buf * (2 * BM * LDT);
+        bf16_t* Ws = As + BM * LDT;
+        const int k0 = slab * BK + lc8;
+        float g[8], b[8];
+        if constexpr (PRO == PRO_LN) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { g[e] = p.gamma[k0 + e]; b[e] = p.beta[k0 + e]; }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u32x4 a = ra[i];
+            if constexpr (PRO == PRO_LN) {
+                float v[8];
+                unpack8(a, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (v[e] - ln_mean[i]) * ln_rstd[i] * g[e] + b[e];
+                a = pack8(v);
+            } else if constexpr (PRO == PRO_DROP) {
+                if (pro_th) {
+                    const uint64_t e0 = (uint64_t)(m0 + lrow + 32 * i) * p.K + k0;
+                    const f32x4 k0v = drop_keep4(p.pro_seed, e0, pro_th, pro_sc);
+                    const f32x4 k1v = drop_keep4(p.pro_seed, e0 + 4, pro_th, pro_sc);
+                    float v[8];
+                    unpack8(a, v);
+                    v[0] *= k0v.x; v[1] *= k0v.y; v[2] *= k0v.z; v[3] *= k0v.w;
+                    v[4] *= k1v.x; v[5] *= k1v.y; v[6] *= k1v.z; v[7] *= k1v.w;
+                    a = pack8(v);
+                }
+            }
+            *reinterpret_cast<u32x4*>(As + (lrow + 32 * i) * LDT + lc8) = a;
+            *reinterpret_cast<u32x4*>(Ws + (lrow + 32 * i) * LDT + lc8) = rw[i];
+        }
+    };
+
+    int t = blockIdx.x;
+    if (t >= n_tiles) return;
+    int64_t m0; int n0;
+    tile_origin(t, m0, n0);
+    issue(m0, n0, 0, true);
+    commit(0, m0, 0);
+    __syncthreads();
+    int buf = 0;
+
+    while (true) {
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+        int tn = t; int64_t mn = m0; int nn = n0;
+        for (int s = 0; s < n_slab; ++s) {
+            bool have_next = true, new_tile = false;
+            int s_next = s + 1;
+            if (s_next == n_slab) {
+                tn = t + gridDim.x;
+                have_next = tn < n_tiles;
+                s_next = 0;
+                new_tile = true;
+                if (have_next) tile_origin(tn, mn, nn);
+            }
+            if (have_next) issue(mn, nn, s_next, new_tile);
+
+            const bf16_t* As = sm + buf * (2 * BM * LDT);
+            const bf16_t* Ws = As + BM * LDT;
+            const bf16_t* ap = As + (wm * 64 + lq) * LDT + 8 * hh;
+            const bf16_t* wp = Ws + (wn * 64 + lq) * LDT + 8 * hh;
+#pragma unroll
+            for (int kk = 0; kk < BK / 16; ++kk) {
+                const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(ap + 16 * kk);
+                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(ap + 32 * LDT + 16 * kk);
+                const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(wp + 16 * kk);
+                const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(wp + 32 * LDT + 16 * kk);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+            }
+            if (have_next) commit(buf ^ 1, mn, s_next);
+            __syncthreads();
+            buf ^= 1;
+        }
+
+        // ---- epilogue through the idle LDS buffer (fp32 staging, [32][68] per wave)
+        {
+            const uint32_t epi_th = drop_thresh(p.epi_p);
+            const float epi_sc = 1.0f / (1.0f - p.epi_p);
+            constexpr int SLD = 68;
+            float* stg = reinterpret_cast<float*>(sm + (buf ^ 1) * (2 * BM * LDT)) + wave * (32 * SLD);
+            const int er = lane >> 4, ec = (lane & 15) * 4;
+            const int col = n0 + wn * 64 + ec;
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_DROP_RES || EPI == EPI_BIAS_GELU_DROP)
+                if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + col);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) stg[crow(r, hh) * SLD + j * 32 + lq] = acc[i][j][r];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll 2
+                for (int ps = 0; ps < 8; ++ps) {
+                    const int rr = ps * 4 + er;
+                    const int64_t off = (m0 + wm * 64 + i * 32 + rr) * p.N + col;
+                    f32x4 v = *reinterpret_cast<const f32x4*>(stg + rr * SLD + ec) + bv;
+                    f32x4 dk = {1.f, 1.f, 1.f, 1.f};
+                    if constexpr (EPI == EPI_BIAS_DROP_RES || EPI == EPI_BIAS_GELU_DROP || EPI == EPI_GELU_BWD) {
+                        if (epi_th) dk = drop_keep4(p.epi_seed, (uint64_t)off, epi_th, epi_sc);
+                    }
+                    float o4[4] = {v.x, v.y, v.z, v.w};
+                    if constexpr (EPI == EPI_BIAS_DROP_RES) {
+                        float rs[4];
+                        io<bf16_t>::load4(p.res + off, rs);
+                        o4[0] = rs[0] + v.x * dk.x; o4[1] = rs[1] + v.y * dk.y;
+                        o4[2] = rs[2] + v.z * dk.z; o4[3] = rs[3] + v.w * dk.w;
+                    } else if constexpr (EPI == EPI_BIAS_GELU_DROP) {
+                        io<bf16_t>::store4(p.C2 + off, o4);
+                        // gelu is evaluated on the bf16-rounded pre-activation that backward will see
+                        float h[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) h[e] = (float)(bf16_t)o4[e];
+                        o4[0] = gelu_f(h[0]) * dk.x; o4[1] = gelu_f(h[1]) * dk.y;
+                        o4[2] = gelu_f(h[2]) * dk.z; o4[3] = gelu_f(h[3]) * dk.w;
+                    } else if constexpr (EPI == EPI_GELU_BWD) {
+                        float h[4];
+                        io<bf16_t>::load4(p.aux + off, h);
+                        o4[0] = v.x * dk.x * gelu_grad(h[0]); o4[1] = v.y * dk.y * gelu_grad(h[1]);
+                        o4[2] = v.z * dk.z * gelu_grad(h[2]); o4[3] = v.w * dk.w * gelu_grad(h[3]);
+                    }
+                    io<bf16_t>::store4(p.C + off, o4);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        __syncthreads();
+        t += gridDim.x;
+        if (t >= n_tiles) break;
+        m0 = mn; n0 = nn;
+    }
+}
+
+// ------------------------------------------------------------------ dW / db (bf16 operands)
+struct TnArgsB {
+    const bf16_t* A; const bf16_t* B; float* dW; float* db;
+    const float* mean; const float* rstd; const float* gamma; const float* beta;
+    int64_t M; int N, K;
+    int n_split; int64_t rows_per_split;
+    uint32_t pro_seed; float pro_p;
+};
+
+constexpr int TMB = 32;              // rows of M per LDS stage (two k16 steps)
+constexpr int LDW = 160;             // LDS row stride in bf16 (320 B): tr-read rows hit disjoint bank quarters
+
+// 8 consecutive m (k index of the MFMA) for column (c0 + lane_in_group) -> one operand fragment
+__device__ __forceinline__ bf16x8 tr_frag(const bf16_t* tile, int m_base, int c0, int lane) {
+    const int il = lane & 15, q = il >> 2, pcol = (il & 3) * 4;
+    const bf16_t* a0 = tile + (m_base + q) * LDW + c0 + pcol;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)a0);
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a0 + 4 * LDW));
+    bf16x8 f = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    return f;
+}
+
+template <int PRO, bool BLN>
+__global__ __launch_bounds__(256, 2) void gemm_tn_bf16_k(TnArgsB p) {
+    __shared__ __attribute__((aligned(16))) bf16_t sm[2 * 2 * TMB * LDW];    // [buf][A|B][32][160]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane & 31, hh = lane >> 5;
+    const int wn = wave >> 1, wk = wave & 1;
+    const int tiles_n = p.N / 128, tiles_k = p.K / 128, n_tiles = tiles_n * tiles_k;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int tile = j % n_tiles;
+    const int split = (j / n_tiles) * 8 + xcd;
+    if (split >= p.n_split) return;
+    const int n0 = (tile / tiles_k) * 128, k0 = (tile % tiles_k) * 128;
+    const int64_t r_begin = (int64_t)split * p.rows_per_split;
+    const int64_t r_end = r_begin + p.rows_per_split < p.M ? r_begin + p.rows_per_split : p.M;
+    if (r_begin >= r_end) return;
+    const int n_it = (int)((r_end - r_begin) / TMB);
+
+    const int lrow = tid >> 4, lc8 = (tid & 15) * 8;           // rows lrow + 16*i, bf16 columns lc8..lc8+7
+    const uint32_t pro_th = drop_thresh(p.pro_p);
+    const float pro_sc = 1.0f / (1.0f - p.pro_p);
+    u32x4 ra[2], rb[2];
+    float bm[2], bs[2];
+    float colsum[8], lg[8], lb[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { colsum[e] = 0.f; lg[e] = 1.f; lb[e] = 0.f; }
+    if constexpr (BLN) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { lg[e] = p.gamma[k0 + lc8 + e]; lb[e] = p.beta[k0 + lc8 + e]; }
+    }
+
+    auto issue = [&](int it) {
+        const int64_t r0 = r_begin + (int64_t)it * TMB + lrow;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            ra[i] = *reinterpret_cast<const u32x4*>(p.A + (r0 + 16 * i) * p.N + n0 + lc8);
+            rb[i] = *reinterpret_cast<const u32x4*>(p.B + (r0 + 16 * i) * p.K + k0 + lc8);
+            if constexpr (BLN) { bm[i] = p.mean[r0 + 16 * i]; bs[i] = p.rstd[r0 + 16 * i]; }
+        }
+    };
+    auto commit = [&](int buf, int it) {
+        bf16_t* As = sm + buf * (2 * TMB * LDW);
+        bf16_t* Bs = As + TMB * LDW;
+        const int64_t r0 = r_begin + (int64_t)it * TMB + lrow;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            u32x4 a = ra[i], b = rb[i];
+            float av[8];
+            unpack8(a, av);
+            if constexpr (PRO == PRO_DROP) {
+                const uint64_t e0 = (uint64_t)(r0 + 16 * i) * p.N + n0 + lc8;
+                const f32x4 k0v = drop_keep4(p.pro_seed, e0, pro_th, pro_sc);
+                const f32x4 k1v = drop_keep4(p.pro_seed, e0 + 4, pro_th, pro_sc);
+                av[0] *= k0v.x; av[1] *= k0v.y; av[2] *= k0v.z; av[3] *= k0v.w;
+                av[4] *= k1v.x; av[5] *= k1v.y; av[6] *= k1v.z; av[7] *= k1v.w;
+                a = pack8(av);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) colsum[e] += av[e];
+            if constexpr (BLN) {
+                float bv[8];
+                unpack8(b, bv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bv[e] = (bv[e] - bm[i]) * bs[i] * lg[e] + lb[e];
+                b = pack8(bv);
+            }
+            *reinterpret_cast<u32x4*>(As + (lrow + 16 * i) * LDW + lc8) = a;
+            *reinterpret_cast<u32x4*>(Bs + (lrow + 16 * i) * LDW + lc8) = b;
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][jj][e] = 0.f;
+
+    issue(0);
+    commit(0, 0);
+    __syncthreads();
+    int buf = 0;
+    const int csub = 16 * ((lane >> 4) & 1);                   // 16-lane group -> column half of a 32-wide fragment
+    for (int it = 0; it < n_it; ++it) {
+        const bool have_next = it + 1 < n_it;
+        if (have_next) issue(it + 1);
+        const bf16_t* As = sm + buf * (2 * TMB * LDW);
+        const bf16_t* Bs = As + TMB * LDW;
+#pragma unroll
+        for (int s = 0; s < TMB / 16; ++s) {
+            const int mb = 16 * s + 8 * hh;
+            const bf16x8 a0 = tr_frag(As, mb, wn * 64 + csub, lane);
+            const bf16x8 a1 = tr_frag(As, mb, wn * 64 + 32 + csub, lane);
+            const bf16x8 b0 = tr_frag(Bs, mb, wk * 64 + csub, lane);
+            const bf16x8 b1 = tr_frag(Bs, mb, wk * 64 + 32 + csub, lane);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (have_next) commit(buf ^ 1, it + 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wn * 64 + i * 32 + crow(r, hh);
+                const int k = k0 + wk * 64 + jj * 32 + lq;
+                atomicAdd(p.dW + (int64_t)n * p.K + k, acc[i][jj][r]);
+            }
+    if (p.db != nullptr && k0 == 0) {
+        float* red = reinterpret_cast<float*>(sm);             // [16][128] partial column sums
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[lrow * 128 + lc8 + e] = colsum[e];
+        __syncthreads();
+        if (tid < 128) {
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) s += red[q * 128 + tid];
+            atomicAdd(p.db + n0 + tid, s);
+        }
+    }
+}
+
+template <int PRO>
+int launch_nt_b(const NtArgsB& a, int epi, int grid, hipStream_t st) {
+    switch (epi) {
+        case EPI_BIAS: gemm_nt_bf16_k<PRO, EPI_BIAS><<<grid, 256, 0, st>>>(a); break;
+        case EPI_BIAS_DROP_RES: gemm_nt_bf16_k<PRO, EPI_BIAS_DROP_RES><<<grid, 256, 0, st>>>(a); break;
+        case EPI_BIAS_GELU_DROP: gemm_nt_bf16_k<PRO, EPI_BIAS_GELU_DROP><<<grid, 256, 0, st>>>(a); break;
+        case EPI_GELU_BWD: gemm_nt_bf16_k<PRO, EPI_GELU_BWD><<<grid, 256, 0, st>>>(a); break;
+        case EPI_NONE: gemm_nt_bf16_k<PRO, EPI_NONE><<<grid, 256, 0, st>>>(a); break;
+        default: return HWGAT_EINVAL;
+    }
+    HWGAT_LAUNCH_CHECK();
+}
+
+}  // namespace
+
+extern "C" int hwgat_linear_nt_bf16(const void* A, const void* W, const float* bias, void* C, int64_t M, int N,
+                                    int K, int pro, const float* mean, const float* rstd, const float* gamma,
+                                    const float* beta, uint32_t pro_seed, float pro_p, int epi, const void* res,
+                                    void* C2, const void* aux, uint32_t epi_seed, float epi_p, void* stream) {
+    if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) return HWGAT_EINVAL;
+    if (M % BM || N % BN || K % BK || (M / BM) * (int64_t)(N / BN) > 0x7fffffff) return HWGAT_ESHAPE;
+    if (pro == PRO_LN && (!mean || !rstd || !gamma || !beta)) return HWGAT_EINVAL;
+    if (epi == EPI_BIAS_DROP_RES && !res) return HWGAT_EINVAL;
+    if (epi == EPI_BIAS_GELU_DROP && !C2) return HWGAT_EINVAL;
+    if (epi == EPI_GELU_BWD && !aux) return HWGAT_EINVAL;
+    if (pro_p < 0.f || pro_p >= 1.f || epi_p < 0.f || epi_p >= 1.f) return HWGAT_EINVAL;
+    NtArgsB a{(const bf16_t*)A, (const bf16_t*)W, bias, (bf16_t*)C, (bf16_t*)C2, (const bf16_t*)res,
+              (const bf16_t*)aux, mean, rstd, gamma, beta, M, N, K, pro_seed, epi_seed, pro_p, epi_p};
+    const int64_t tiles = (M / BM) * (N / BN);
+    const int grid = (int)(tiles < 512 ? tiles : 512);
+    hipStream_t st = (hipStream_t)stream;
+    switch (pro) {
+        case PRO_NONE: return launch_nt_b<PRO_NONE>(a, epi, grid, st);
+        case PRO_LN: return launch_nt_b<PRO_LN>(a, epi, grid, st);
+        case PRO_DROP: return launch_nt_b<PRO_DROP>(a, epi, grid, st);
+        default: return HWGAT_EINVAL;
+    }
+}
+
+extern "C" int hwgat_linear_tn_bf16(const void* A, const void* B, float* dW, float* db, int64_t M, int N, int K,
+                                    uint32_t pro_seed, float pro_p, const float* mean, const float* rstd,
+                                    const float* gamma, const float* beta, void* stream) {
+    if (!A || !B || !dW || M <= 0 || N <= 0 || K <= 0) return HWGAT_EINVAL;
+    if (mean && (!rstd || !gamma || !beta)) return HWGAT_EINVAL;
+    if (M % TMB || N % 128 || K % 128) return HWGAT_ESHAPE;
+    if (pro_p < 0.f || pro_p >= 1.f) return HWGAT_EINVAL;
+    const int n_tiles = (N / 128) * (K / 128);
+    auto gcd = [](int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; };
+    const int r_min = n_tiles / gcd(n_tiles, 512);
+    int r = r_min;
+    while (r < 2) r += r_min;
+    int64_t want = (int64_t)512 * r / n_tiles;
+    const int64_t max_split = M / (TMB * 16) > 0 ? M / (TMB * 16) : 1;
+    if (want > max_split) want = max_split;
+    if (want < 1) want = 1;
+    int64_t rows = (M + want - 1) / want;
+    rows = (rows + TMB - 1) / TMB * TMB;
+    const int n_split = (int)((M + rows - 1) / rows);
+    TnArgsB a{(const bf16_t*)A, (const bf16_t*)B, dW, db, mean, rstd, gamma, beta, M, N, K, n_split, rows,
+              pro_seed, pro_p};
+    const int grid = ((n_split + 7) / 8) * 8 * n_tiles;
+    hipStream_t st = (hipStream_t)stream;
+    if (pro_p > 0.f) {
+        if (mean) gemm_tn_bf16_k<PRO_DROP, true><<<grid, 256, 0, st>>>(a);
+        else gemm_tn_bf16_k<PRO_DROP, false><<<grid, 256, 0, st>>>(a);
+    } else {
+        if (mean) gemm_tn_bf16_k<PRO_NONE, true><<<grid, 256, 0, st>>>(a);
+        else gemm_tn_bf16_k<PRO_NONE, false><<<grid, 256, 0, st>>>(a);
+    }
+    HWGAT_LAUNCH_CHECK();
+}

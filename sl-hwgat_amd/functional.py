@@ -193,12 +193,14 @@ def linear_nt(A, W, bias=None, *, pro=PRO_NONE, ln=None, pro_seed=0, pro_p=0.0, 
     K = A.shape[-1]
     M = A.numel() // K
     N = W.shape[0]
-    C = out if out is not None else torch.empty(*A.shape[:-1], N, device=A.device, dtype=torch.float32)
+    if W.dtype != A.dtype:
+        raise TypeError("weight must already be in the activation dtype (cast once per step)")
+    C = out if out is not None else torch.empty(*A.shape[:-1], N, device=A.device, dtype=A.dtype)
     C2 = torch.empty_like(C) if epi == EPI_BIAS_GELU_DROP else None
     mean = rstd = gamma = beta = None
     if pro == PRO_LN:
         mean, rstd, gamma, beta = ln
-    call("hwgat_linear_nt_f32", ptr(A), ptr(W), ptr(bias), ptr(C), M, N, K, pro, ptr(mean), ptr(rstd),
+    call("hwgat_linear_nt_f32" if A.dtype == torch.float32 else "hwgat_linear_nt_bf16", ptr(A), ptr(W), ptr(bias), ptr(C), M, N, K, pro, ptr(mean), ptr(rstd),
          ptr(gamma), ptr(beta), pro_seed & 0xFFFFFFFF, float(pro_p), epi, ptr(res), ptr(C2), ptr(aux),
          epi_seed & 0xFFFFFFFF, float(epi_p), stream())
     return (C, C2) if C2 is not None else C
@@ -210,7 +212,7 @@ def linear_tn(A, Bm, dW, db=None, *, pro_seed=0, pro_p=0.0, ln=None):
     N, K = dW.shape
     M = A.numel() // N
     mean, rstd, gamma, beta = ln if ln is not None else (None, None, None, None)
-    call("hwgat_linear_tn_f32", ptr(A), ptr(Bm), ptr(dW), ptr(db), M, N, K, pro_seed & 0xFFFFFFFF,
+    call("hwgat_linear_tn_f32" if A.dtype == torch.float32 else "hwgat_linear_tn_bf16", ptr(A), ptr(Bm), ptr(dW), ptr(db), M, N, K, pro_seed & 0xFFFFFFFF,
          float(pro_p), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), stream())
 
 
@@ -233,11 +235,12 @@ def ln_backward(dy, x, mean, rstd, gamma, dres, dgamma, dbeta):
     return dx
 
 
-def transpose(W):
+def transpose(W, dtype=torch.float32):
+    """W^T of a (small) weight, optionally cast to the activation dtype"""
     R, C = W.shape
     out = torch.empty(C, R, device=W.device, dtype=torch.float32)
     call("hwgat_transpose_f32", ptr(W), ptr(out), R, C, stream())
-    return out
+    return out if dtype == torch.float32 else out.to(dtype)
 
 
 def dropout_mask(shape, seed, p, device):

@@ -101,3 +101,75 @@ def test_transpose():
     assert torch.equal(HF.transpose(W.to(DEV)).cpu(), W.t().contiguous())
     W = torch.randn(100, 37)
     assert torch.equal(HF.transpose(W.to(DEV)).cpu(), W.t().contiguous())
+
+
+# ------------------------------------------------------------------ bf16 family (config 3)
+BT = 6e-3      # bf16 output rounding (2^-9) dominates; accumulation is fp32
+
+
+def _b(x):
+    return x.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (640, 384, 128), (1152, 256, 512), (128 * 600, 128, 128)])
+def test_bf16_nt_plain_bias_ln(M, N, K):
+    A, W, b = _data(M, N, K, M + K)
+    Ab, Wb = _b(A), _b(W)
+    ref = Ab.double() @ Wb.double().t()
+    got = HF.linear_nt(Ab.to(DEV), Wb.to(DEV), None, epi=HF.EPI_NONE)
+    assert got.dtype == torch.bfloat16 and rel_err(got.float().cpu(), ref) < BT
+    got = HF.linear_nt(Ab.to(DEV), Wb.to(DEV), b.to(DEV), epi=HF.EPI_BIAS)
+    assert rel_err(got.float().cpu(), ref + b.double()) < BT
+    if K >= 128:
+        g = torch.Generator().manual_seed(9)
+        gamma, beta = torch.randn(K, generator=g), torch.randn(K, generator=g)
+        mean, rstd = HF.ln_stats(Ab.to(DEV), gamma.to(DEV), beta.to(DEV))
+        xn = torch.nn.functional.layer_norm(Ab.double(), (K,), gamma.double(), beta.double())
+        got = HF.linear_nt(Ab.to(DEV), Wb.to(DEV), b.to(DEV), pro=HF.PRO_LN,
+                           ln=(mean, rstd, gamma.to(DEV), beta.to(DEV)))
+        # the normalised operand is rounded to bf16 before the MFMA
+        assert rel_err(got.float().cpu(), _b(xn.float()).double() @ Wb.double().t() + b.double()) < BT
+
+
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_bf16_nt_epilogues(p):
+    M, N, K = 512, 256, 128
+    A, W, b = _data(M, N, K, 5)
+    Ab, Wb = _b(A).to(DEV), _b(W).to(DEV)
+    res = _b(torch.randn(M, N, generator=torch.Generator().manual_seed(2)))
+    mask = HF.dropout_mask((M, N), 1234, p, DEV).cpu().double()
+    lin = Ab.cpu().double() @ Wb.cpu().double().t() + b.double()
+    got = HF.linear_nt(Ab, Wb, b.to(DEV), epi=HF.EPI_BIAS_DROP_RES, res=res.to(DEV), epi_seed=1234, epi_p=p)
+    assert rel_err(got.float().cpu(), res.double() + lin * mask) < BT
+    u, h1 = HF.linear_nt(Ab, Wb, b.to(DEV), epi=HF.EPI_BIAS_GELU_DROP, epi_seed=1234, epi_p=p)
+    assert rel_err(h1.float().cpu(), lin) < BT
+    assert rel_err(u.float().cpu(), torch.nn.functional.gelu(h1.float().cpu().double()) * mask) < BT
+    dy = _b(torch.randn(M, K, generator=torch.Generator().manual_seed(4)))
+    h1r = h1.float().cpu().double().requires_grad_(True)
+    torch.nn.functional.gelu(h1r).sum().backward()
+    ref = (dy.double() @ Wb.cpu().double().t()) * mask * h1r.grad
+    got = HF.linear_nt(dy.to(DEV), Wb, None, epi=HF.EPI_GELU_BWD, aux=h1, epi_seed=1234, epi_p=p)
+    assert rel_err(got.float().cpu(), ref) < BT
+    maskA = HF.dropout_mask((M, K), 77, p, DEV).cpu().double()
+    got = HF.linear_nt(Ab, Wb, None, pro=HF.PRO_DROP, pro_seed=77, pro_p=p, epi=HF.EPI_NONE)
+    assert rel_err(got.float().cpu(), _b((Ab.cpu().double() * maskA).float()).double() @ Wb.cpu().double().t()) < BT
+
+
+@pytest.mark.parametrize("M,N,K,p", [(512, 128, 128, 0.0), (4096, 384, 128, 0.0), (32 * 301, 256, 512, 0.1), (65536, 128, 256, 0.0)])
+def test_bf16_tn_weight_and_bias_grad(M, N, K, p):
+    g = torch.Generator().manual_seed(M + K)
+    dY, X = _b(torch.randn(M, N, generator=g)), _b(torch.randn(M, K, generator=g))
+    mask = HF.dropout_mask((M, N), 5, p, DEV).cpu().double() if p > 0 else torch.ones(M, N, dtype=torch.float64)
+    dW = torch.zeros(N, K, device=DEV)
+    db = torch.zeros(N, device=DEV)
+    HF.linear_tn(dY.to(DEV), X.to(DEV), dW, db, pro_seed=5, pro_p=p)
+    dYm = _b((dY.double() * mask).float()).double() if p > 0 else dY.double()
+    assert rel_err(dW.cpu(), dYm.t() @ X.double()) < 1e-4          # fp32 accumulate of exact bf16 products
+    assert rel_err(db.cpu(), (dY.double() * mask).sum(0)) < 1e-4
+    # LayerNorm prologue on B
+    gamma, beta = torch.randn(K, generator=g), torch.randn(K, generator=g)
+    mean, rstd = HF.ln_stats(X.to(DEV), gamma.to(DEV), beta.to(DEV))
+    dW.zero_()
+    HF.linear_tn(dY.to(DEV), X.to(DEV), dW, None, ln=(mean, rstd, gamma.to(DEV), beta.to(DEV)))
+    xn = _b(torch.nn.functional.layer_norm(X.double(), (K,), gamma.double(), beta.double()).float()).double()
+    assert rel_err(dW.cpu(), dY.double().t() @ xn) < 2e-3

@@ -143,15 +143,28 @@ def test_fresh_inputs_vs_oracle_and_raw_joint_path():
 
 
 def test_bf16_activations_config3_tolerance():
+    """BASELINE config 3: bf16 activations + bf16 MFMA projections vs the fp32 reference vectors"""
     fx = load_fixture("cfg1.npz")
     model, cfg = build(fx)
     model.eval().set_activation_dtype(torch.bfloat16)
-    x = torch.from_numpy(fx["x"]).to(DEV)
-    with torch.no_grad():
-        logits = model(x)
-    err = rel_err(logits.float().cpu(), fx["eval.logits"])
-    print("bf16 logits rel err", err)
+    x, y = torch.from_numpy(fx["x"]).to(DEV), torch.from_numpy(fx["y"]).to(DEV)
+    out = model(x)
+    loss = O.smoothed_cross_entropy(out.float(), y)
+    loss.backward()
+    err = rel_err(out.float().detach().cpu(), fx["eval.logits"])
+    print("bf16 logits rel err", err, "loss", loss.item(), "ref", float(fx["evalbwd.loss"]))
     assert err < 3e-2
+    assert abs(loss.item() - float(fx["evalbwd.loss"])) < 3e-2
+    # gradients: bf16 error accumulates through 8 blocks of backward; check norms to 10 %
+    worst = 0.0
+    for name, prm in model.named_parameters():
+        key = "evalbwd.gn." + name
+        if prm.grad is None or key not in fx:
+            continue
+        ref_norm = fx[key][0]
+        worst = max(worst, abs(prm.grad.double().norm().item() - ref_norm) / max(ref_norm, 1e-12))
+    print("bf16 worst grad-norm rel err", worst)
+    assert worst < 0.1
 
 
 def test_dropout_train_mode_runs_and_is_stochastic():
