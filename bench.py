@@ -23,7 +23,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-CFG = dict(B=64, T=128, J=67, nW=5, C=2, d0=128, nc=2002)
+CFG = dict(B=64, T=128, J=67, nW=5, C=2, d0=128, nc=2002)                     # BASELINE configs[1] (and [2] in bf16)
+CFG5 = dict(B=256, T=256, J=133, nW=7, C=3, d0=256, nc=2002)                  # BASELINE configs[4] "stress"
 HBM_PEAK = 8.0e12           # B/s, MI355X_MICROARCH.md
 F32_MFMA_PEAK = 157.3e12    # FLOP/s
 
@@ -74,7 +75,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
-    ap.add_argument("--batch", type=int, default=CFG["B"], help="clips per GPU")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 5],
+                    help="BASELINE config: 2 = fp32 headline (default), 3 = same in bf16, 5 = stress shape")
+    ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default: the config's)")
+    ap.add_argument("--micro-batch", type=int, default=None, help="gradient-accumulation slice (clips)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eval-mode", action="store_true", help="deterministic fwd+bwd (no dropout / attention drop)")
     args = ap.parse_args()
@@ -98,7 +102,12 @@ def main():
     dist_mod = import_module("sl-hwgat_amd.dist")
     HF = hw.functional
 
-    c = dict(CFG, B=args.batch)
+    if args.config == 3:
+        args.dtype = "bf16"
+    base = CFG5 if args.config == 5 else CFG
+    c = dict(base, B=args.batch or base["B"])
+    if args.config == 5 and args.micro_batch is None:
+        args.micro_batch = 16 if args.dtype == "f32" else 32      # activation memory, DESIGN.md section 3
     torch.manual_seed(1001)                                       # reference configs.py:55-59
     hp = hw.HWGATEParams({"src_len": c["T"], "num_class": c["nc"]}, c["C"], dev, num_kps=c["nW"] * 16,
                          embed_dim=c["d0"])
@@ -110,7 +119,7 @@ def main():
     dist_mod.broadcast_parameters(model)
     reducer = dist_mod.GradReducer(model.parameters()) if world > 1 else None
     opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=5e-4, fused=True)
-    step = train_mod.TrainStep(model, opt, reducer)
+    step = train_mod.TrainStep(model, opt, reducer, micro_batch=args.micro_batch)
 
     g = torch.Generator(device=dev).manual_seed(7 + rank)
     x = torch.rand(c["B"], c["T"], c["J"], c["C"], device=dev, generator=g)
@@ -141,7 +150,8 @@ def main():
 
     if rank == 0:
         itemsize = 4 if args.dtype == "f32" else 2
-        E = c["B"] * c["T"] * c["nW"] * 16 * c["d0"]
+        b_launch = min(args.micro_batch or c["B"], c["B"])            # clips per attention launch
+        E = b_launch * c["T"] * c["nW"] * 16 * c["d0"]
         kern = {}
         for name, bwd in (("hwgat_win_attn_fwd", False), ("hwgat_win_attn_bwd", True)):
             n, ms = timers.get(name, (0, 0.0))
@@ -174,17 +184,18 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: HWGAT train step (fwd+loss+bwd+AdamW), "
+            "config": {"workload": f"BASELINE configs[{ {2: 1, 3: 2, 5: 4}[args.config] }]: HWGAT train step (fwd+loss+bwd+AdamW), "
                                    f"B={c['B']}/GPU T={c['T']} J={c['J']}->K={c['nW'] * 16} C={c['C']} "
                                    f"d_model={c['d0']} depths[2,2,4] classes={c['nc']}, "
-                                   + ("eval-mode" if args.eval_mode else "train-mode drop 0.1"),
+                                   + ("eval-mode" if args.eval_mode else "train-mode drop 0.1")
+                                   + (f", micro-batch {args.micro_batch}" if args.micro_batch else ""),
                        "global_batch": world * c["B"], "parallelism": f"dp{world}"},
             "roofline": roof,
             "kernels": kern, "other_hip_entry_points": others,
             "hip_kernel_ms_per_step": round(hip_ms / args.steps, 3),
             "loss": round(loss, 4),
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.config != 5:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     if world > 1:

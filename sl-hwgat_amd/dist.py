@@ -66,11 +66,14 @@ class GradReducer:
                 h = dist.all_reduce(bucket["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self._handles.append(h)
 
-    def zero_grad(self):
-        """call instead of optimizer.zero_grad(): keeps the bucket views alive"""
+    def zero_grad(self, n_accum: int = 1):
+        """call instead of optimizer.zero_grad(): keeps the bucket views alive.
+        `n_accum`: number of backward passes (micro-batches) that accumulate into the buckets
+        before they are reduced; a bucket is launched when its last gradient of the LAST pass lands."""
+        self._n_accum = n_accum
         for b in self.buckets:
             b["flat"].zero_()
-            b["pending"] = len(b["params"])
+            b["pending"] = len(b["params"]) * n_accum
             for p in b["params"]:                            # re-attach if something replaced .grad
                 if p.grad is None or p.grad.data_ptr() < b["flat"].data_ptr() or \
                         p.grad.data_ptr() >= b["flat"].data_ptr() + b["flat"].numel() * b["flat"].element_size():
@@ -80,7 +83,7 @@ class GradReducer:
     def finish(self):
         """wait for every bucket (call after backward, before optimizer.step)."""
         for b in self.buckets:
-            if b["pending"] != 0 and b["pending"] != len(b["params"]):
+            if b["pending"] != 0 and b["pending"] != len(b["params"]) * getattr(self, "_n_accum", 1):
                 # some parameters of this bucket got no gradient this step: reduce what is there
                 self._launch(b)
         for h in self._handles:

@@ -21,26 +21,41 @@ class TrainStep:
     """zero_grad -> forward -> loss -> backward (-> bucketed all-reduce) -> optimizer.
 
     Unlike utils.train (utils.py:109,114) nothing here reads a value back to the
-    host: loss and correct-count stay on the device until the caller asks."""
+    host: loss and correct-count stay on the device until the caller asks.
 
-    def __init__(self, model, optimizer=None, reducer=None, criterion=None):
+    `micro_batch`: process the batch in slices of that many clips and accumulate gradients
+    (same mean-loss gradient).  Activations saved for backward are 10*E floats per block
+    (DESIGN.md section 3); BASELINE config 5 (B=256, T=256, K=112, d0=256) would need ~600 GB
+    in one piece, 16-clip slices need ~38 GB."""
+
+    def __init__(self, model, optimizer=None, reducer=None, criterion=None, micro_batch=None):
         self.model, self.opt, self.reducer = model, optimizer, reducer
         self.criterion = criterion or SmoothedCrossEntropyLoss()
+        self.micro_batch = micro_batch
         self.loss = None
         self.correct = None
 
     def __call__(self, x, y):
+        n = x.shape[0]
+        mb = self.micro_batch if self.micro_batch and self.micro_batch < n else n
+        n_acc = (n + mb - 1) // mb
         if self.reducer is not None:
-            self.reducer.zero_grad()
+            self.reducer.zero_grad(n_acc)
         elif self.opt is not None:
             self.opt.zero_grad(set_to_none=True)
-        out = self.model(x)
-        loss = self.criterion(out, y)
-        loss.backward()
+        total = None
+        correct = None
+        for i in range(0, n, mb):
+            xs, ys = x[i:i + mb], y[i:i + mb]
+            out = self.model(xs)
+            loss = self.criterion(out, ys) * (xs.shape[0] / n)
+            loss.backward()
+            total = loss.detach() if total is None else total + loss.detach()
+            c = (out.detach().argmax(-1) == ys).sum()
+            correct = c if correct is None else correct + c
         if self.reducer is not None:
             self.reducer.finish()
         if self.opt is not None:
             self.opt.step()
-        self.loss = loss.detach()
-        self.correct = (out.detach().argmax(-1) == y).sum()
+        self.loss, self.correct = total, correct
         return self.loss

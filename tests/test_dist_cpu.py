@@ -87,3 +87,16 @@ def test_single_process_reducer_is_a_noop_wrapper():
     assert lin.weight.grad.data_ptr() >= red.buckets[-1]["flat"].data_ptr() or len(red.buckets) > 1
     red.zero_grad()
     assert float(lin.weight.grad.abs().sum()) == 0.0
+
+
+def test_reducer_with_gradient_accumulation():
+    dmod = importlib.import_module("sl-hwgat_amd.dist")
+    lin = torch.nn.Linear(8, 4)
+    red = dmod.GradReducer(lin.parameters(), bucket_bytes=64)
+    red.zero_grad(n_accum=3)
+    for _ in range(3):
+        lin(torch.ones(2, 8)).sum().backward()
+        assert all(b["pending"] >= 0 for b in red.buckets)
+    assert all(b["pending"] == 0 for b in red.buckets)
+    red.finish()
+    assert torch.allclose(lin.weight.grad, torch.full((4, 8), 6.0))

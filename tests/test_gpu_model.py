@@ -217,3 +217,20 @@ def test_fused_dropout_matches_unfused_math_with_same_masks():
     assert rel_err(gx.cpu(), xr.grad.cpu()) < 1e-4
     for n, q in blk.named_parameters():
         assert rel_err(grads[n].cpu(), q.grad.cpu()) < 1e-4, n
+
+
+def test_micro_batched_step_equals_full_batch_step():
+    from importlib import import_module
+    tr = import_module("sl-hwgat_amd.train")
+    fx = load_fixture("cfg1.npz")
+    x, y = torch.from_numpy(fx["x"]).to(DEV), torch.from_numpy(fx["y"]).to(DEV)
+    grads = []
+    for mb in (None, 1):
+        model, cfg = build(fx)
+        model.eval()
+        step = tr.TrainStep(model, None, None, micro_batch=mb)
+        step(x, y)
+        grads.append({k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+        assert abs(float(step.loss) - float(fx["evalbwd.loss"])) < 1e-4
+    for k in grads[0]:
+        assert rel_err(grads[1][k].cpu(), grads[0][k].cpu()) < 1e-4, k
