@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default: the config's)")
     ap.add_argument("--micro-batch", type=int, default=None, help="gradient-accumulation slice (clips)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timers", action="store_true", help="skip the per-launch HIP events (A/B runs)")
     ap.add_argument("--eval-mode", action="store_true", help="deterministic fwd+bwd (no dropout / attention drop)")
     args = ap.parse_args()
 
@@ -92,8 +93,14 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
-    if world > 1:
+    # HWGAT_FORCE_DIST=1: run the RCCL path (process group, broadcast, bucketed all-reduce) even at
+    # world size 1 -- lets a 1-GPU box rehearse exactly what the N>1 launch executes
+    use_dist = world > 1 or os.environ.get("HWGAT_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     hw = importlib.import_module("sl-hwgat_amd")
@@ -117,7 +124,7 @@ def main():
         model.set_activation_dtype(torch.bfloat16)
     model.train(not args.eval_mode)
     dist_mod.broadcast_parameters(model)
-    reducer = dist_mod.GradReducer(model.parameters()) if world > 1 else None
+    reducer = dist_mod.GradReducer(model.parameters(), always_reduce=use_dist) if use_dist else None
     opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=5e-4, fused=True)
     step = train_mod.TrainStep(model, opt, reducer, micro_batch=args.micro_batch)
 
@@ -126,14 +133,14 @@ def main():
     y = torch.randint(0, c["nc"], (c["B"],), device=dev, generator=g)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step(x, y)
     barrier()
-    HF.TIMERS = {}
+    HF.TIMERS = None if args.no_kernel_timers else {}
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(x, y)
@@ -144,7 +151,7 @@ def main():
     loss = float(step.loss)
 
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t)
 
@@ -198,7 +205,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.config != 5:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

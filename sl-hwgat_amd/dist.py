@@ -19,8 +19,9 @@ import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, params, bucket_bytes: int = 16 << 20, group=None):
+    def __init__(self, params, bucket_bytes: int = 16 << 20, group=None, always_reduce: bool = False):
         self.group = group
+        self.always_reduce = always_reduce          # issue the collectives even at world size 1 (rehearsal)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         params = [p for p in params if p.requires_grad]
         order = list(reversed(params))                       # backward visits parameters roughly in reverse
@@ -58,7 +59,7 @@ class GradReducer:
         return hook
 
     def _launch(self, bucket):
-        if self.world > 1:
+        if self.world > 1 or (self.always_reduce and dist.is_initialized()):
             if self._use_avg:
                 h = dist.all_reduce(bucket["flat"], op=dist.ReduceOp.AVG, group=self.group, async_op=True)
             else:
@@ -93,7 +94,7 @@ class GradReducer:
 
 def broadcast_parameters(module, src: int = 0, group=None):
     """make every rank start from rank `src`'s parameters and buffers"""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized():
         return
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src=src, group=group)

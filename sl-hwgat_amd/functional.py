@@ -25,6 +25,10 @@ def call(name, *args):
     TIMERS.setdefault(name, []).append((e0, e1))
 
 
+def TIMERS_ACTIVE():
+    return TIMERS is not None
+
+
 def timers_summary():
     """{entry point: (launches, total_ms)}; synchronises."""
     torch.cuda.synchronize()

@@ -234,3 +234,34 @@ def test_micro_batched_step_equals_full_batch_step():
         assert abs(float(step.loss) - float(fx["evalbwd.loss"])) < 1e-4
     for k in grads[0]:
         assert rel_err(grads[1][k].cpu(), grads[0][k].cpu()) < 1e-4, k
+
+
+def test_pinned_batcher_feeds_raw_joints_through_device_gather():
+    """DataLoader collate -> pinned staging -> async H2D -> device part gather == host WindowCreate path"""
+    from importlib import import_module
+    from torch.utils.data import DataLoader
+    col = import_module("sl-hwgat_amd.collate")
+    T, C, nc = 16, 2, 4
+    g = torch.Generator().manual_seed(3)
+    data = [(torch.rand(T, 29, C, generator=g).numpy(), int(i % nc)) for i in range(10)]
+    hp = hw.HWGATEParams({"src_len": T, "num_class": nc}, C, DEV, num_kps=64)
+    hp.drop_rate = 0.0
+    model = hw.Model(*hp.get_model_params()).eval()
+    idx = hw.part_table(29)
+    batcher = col.PinnedBatcher(4, (T, 29, C), DEV)
+    loader = DataLoader(data, batch_size=4, collate_fn=batcher.collate, num_workers=0)
+    seen = 0
+    for xb, yb in loader:
+        assert xb.is_cuda and xb.shape[1:] == (T, 29, C)
+        n = xb.shape[0]
+        ref_x = torch.stack([torch.from_numpy(d[0]) for d in data[seen:seen + n]]).float()
+        assert torch.equal(xb.cpu(), ref_x) and yb.cpu().tolist() == [d[1] for d in data[seen:seen + n]]
+        with torch.no_grad():
+            model.part_index = None
+            a = model(ref_x[:, :, idx.long()].to(DEV))          # host-side gather (what WindowCreate does)
+            model.use_part_table(idx)
+            b = model(xb)                                       # device-side gather
+        batcher.release()
+        assert rel_err(b.cpu(), a.cpu()) < 1e-5
+        seen += n
+    assert seen == 10
