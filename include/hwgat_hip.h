@@ -52,10 +52,12 @@ int hwgat_debug_mfma32x32x2(const float* a, const float* b, float* out, void* st
  *   pe   (T, d0) fp32 sinusoid table or NULL (pe=False)
  *   out  (B, T, K, d0) `dtype`
  *   out[..., m] = sin(p_m) + pe, out[..., d0/2+m] = cos(p_m) + pe,
- *   p_m = sum_c (2*pi*x_c) * bmat[m][c]  (fp32, accurate range reduction). */
+ *   p_m = sum_c (2*pi*x_c) * bmat[m][c]  (fp32, accurate range reduction).
+ *   drop_p > 0: PositionalEncoding's Dropout (HWGATE.py:28) applied in the same pass with the
+ *   hash mask of the fused linears (element index = flat index of `out`, seed `seed`). */
 int hwgat_embed_fwd(const float* x, const int32_t* idx, const float* bmat, const float* pe,
                     void* out, int B, int T, int J, int K, int C, int d0, int dtype,
-                    void* stream);
+                    uint32_t seed, float drop_p, void* stream);
 
 /* ---- LayerNorm over the last axis (HWGATE.py:203, 219, 353), eps 1e-5.
  *   x, y (N, d) `dtype`; gamma, beta (d) fp32; mean, rstd (N) fp32 (saved

@@ -10,6 +10,7 @@
 //
 // merge: TemporalMerging (HWGATE.py:55-63) as a 16-byte-vector permutation copy.
 #include "common.h"
+#include "fused_ops.h"
 
 namespace {
 
@@ -17,12 +18,14 @@ template <typename T, int C>
 __global__ __launch_bounds__(256) void embed_fwd_k(const float* __restrict__ x, const int32_t* __restrict__ idx,
                                                    const float* __restrict__ bmat, const float* __restrict__ pe,
                                                    T* __restrict__ out, int64_t n_tok, int T_, int J, int K,
-                                                   int d0) {
+                                                   int d0, uint32_t seed, float drop_p) {
     const int half = d0 >> 1;
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nwave = (int64_t)gridDim.x * 4;
     constexpr float TWO_PI = 6.283185307179586f;            // float(2.*torch.pi), HWGATE.py:343
+    const uint32_t dth = drop_thresh(drop_p);               // PositionalEncoding's Dropout (HWGATE.py:28)
+    const float dsc = 1.0f / (1.0f - drop_p);
     for (int m0 = 0; m0 < half; m0 += 64) {
         const int m = m0 + lane;
         const bool act = m < half;
@@ -41,6 +44,10 @@ __global__ __launch_bounds__(256) void embed_fwd_k(const float* __restrict__ x, 
             float sn, cs;
             sincosf(p, &sn, &cs);
             if (pe) { sn += pe[t * d0 + m]; cs += pe[t * d0 + half + m]; }
+            if (dth) {
+                sn *= drop_keep(seed, (uint64_t)tok * d0 + m, dth, dsc);
+                cs *= drop_keep(seed, (uint64_t)tok * d0 + half + m, dth, dsc);
+            }
             if (act) {
                 io<T>::st(out + tok * d0 + m, sn);
                 io<T>::st(out + tok * d0 + half + m, cs);
@@ -73,13 +80,14 @@ __global__ __launch_bounds__(256) void merge_k(const T* __restrict__ in, T* __re
 }  // namespace
 
 extern "C" int hwgat_embed_fwd(const float* x, const int32_t* idx, const float* bmat, const float* pe, void* out,
-                               int B, int T, int J, int K, int C, int d0, int dtype, void* stream) {
-    if (!x || !bmat || !out || B <= 0 || T <= 0 || J <= 0 || K <= 0) return HWGAT_EINVAL;
+                               int B, int T, int J, int K, int C, int d0, int dtype, uint32_t seed, float drop_p,
+                               void* stream) {
+    if (!x || !bmat || !out || B <= 0 || T <= 0 || J <= 0 || K <= 0 || drop_p < 0.f || drop_p >= 1.f) return HWGAT_EINVAL;
     if (d0 <= 0 || (d0 & 1) || (!idx && J != K) || (C != 2 && C != 3)) return HWGAT_ESHAPE;
     hipStream_t st = (hipStream_t)stream;
     const int64_t n_tok = (int64_t)B * T * K;
     const int grid = (int)(n_tok / 4 < 2048 ? (n_tok + 3) / 4 : 2048);
-#define GO(TT, CC) embed_fwd_k<TT, CC><<<grid, 256, 0, st>>>(x, idx, bmat, pe, (TT*)out, n_tok, T, J, K, d0)
+#define GO(TT, CC) embed_fwd_k<TT, CC><<<grid, 256, 0, st>>>(x, idx, bmat, pe, (TT*)out, n_tok, T, J, K, d0, seed, drop_p)
     if (dtype == HWGAT_F32) { if (C == 2) GO(float, 2); else GO(float, 3); }
     else if (dtype == HWGAT_BF16) { if (C == 2) GO(bf16_t, 2); else GO(bf16_t, 3); }
     else return HWGAT_EDTYPE;

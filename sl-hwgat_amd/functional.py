@@ -59,13 +59,13 @@ def mask_bits(adj: torch.Tensor) -> torch.Tensor:
 
 
 # ---------------------------------------------------------------- embedding
-def embed(x, idx, bmat, pe, K, out_dtype=torch.float32):
-    """gather + Fourier features + PE (no gradient: B is frozen, PE a buffer)."""
+def embed(x, idx, bmat, pe, K, out_dtype=torch.float32, drop_p=0.0, seed=0):
+    """gather + Fourier features + PE (+ dropout) (no gradient: B is frozen, PE a buffer)."""
     B, T, J, C = x.shape
     d0 = bmat.shape[0] * 2
     out = torch.empty(B, T, K, d0, device=x.device, dtype=out_dtype)
     call("hwgat_embed_fwd", ptr(x), ptr(idx), ptr(bmat), ptr(pe), ptr(out),
-         B, T, J, K, C, d0, dtype_code(out), stream())
+         B, T, J, K, C, d0, dtype_code(out), seed & 0xFFFFFFFF, float(drop_p), stream())
     return out
 
 

@@ -178,12 +178,11 @@ class Model(nn.Module):
             idx = self.part_index
         x = x.contiguous().float()
         pe = self.pos_encoder.pe.view(self.temporal_dim, self.embed_dim) if self.pe else None
-        h = HF.embed(x, idx, self.B, pe, self.num_kps, self.activation_dtype)
-        if self.pe:
-            h = self._drop(h)
-        k = 0
         if self.training:
             self._drop_calls += 1
+        p_pe = self.drop_rate if (self.training and self.pe) else 0.0     # Dropout lives in PositionalEncoding
+        h = HF.embed(x, idx, self.B, pe, self.num_kps, self.activation_dtype, p_pe, self._seeds(63)[0])
+        k = 0
         for i, stage in enumerate(self.layers):
             for j, blk in enumerate(stage.blocks):
                 thr = None
