@@ -34,9 +34,44 @@ __device__ __forceinline__ uint32_t drop_thresh(float p) {
     return p <= 0.f ? 0u : (uint32_t)fminf(p * 65536.0f + 0.5f, 65535.0f);
 }
 
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
+// Exact-erf GELU (nn.GELU default, HWGATE.py:132) and its derivative.  erf is evaluated branch-free
+// with Abramowitz-Stegun 7.1.26: erf(z) = 1 - (a1 t + ... + a5 t^5) exp(-z^2), t = 1/(1 + p z), z >= 0,
+// |error| <= 1.5e-7 (fp32-rounding level; libm's erff costs ~4x the instructions and made the GELU
+// epilogues VALU-bound).  With z = |x|/sqrt(2) the exponential exp(-x^2/2) is shared with the
+// Gaussian pdf term of the derivative.
+__device__ __forceinline__ void gelu_parts(float x, float& cdf, float& pdf) {
+    const float ax = fabsf(x);
+    const float e = __expf(-0.5f * x * x);                             // exp(-z^2), z = |x|/sqrt(2)
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.7071067811865476f, ax, 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float erfc_half = 0.5f * poly * t * e;                        // 0.5 * erfc(z)
+    cdf = x >= 0.f ? 1.0f - erfc_half : erfc_half;                      // Phi(x) = 0.5 (1 + erf(x/sqrt2))
+    pdf = 0.3989422804014327f * e;
+}
+__device__ __forceinline__ float gelu_f(float x) {
+    float cdf, pdf;
+    gelu_parts(x, cdf, pdf);
+    return x * cdf;
+}
 __device__ __forceinline__ float gelu_grad(float x) {
-    const float cdf = 0.5f * (1.0f + erff(x * 0.7071067811865476f));
-    return cdf + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+    float cdf, pdf;
+    gelu_parts(x, cdf, pdf);
+    return fmaf(x, pdf, cdf);
 }
 
+// Tiling configuration of the linear kernels: WM x WN waves, each owning TM x TN MFMA tiles of
+// 32x32; BK = K-slab depth in elements; OCC = resident blocks per CU the launch bounds ask for;
+// EPV = elements per 16-byte staging vector (4 fp32, 8 bf16); PAD = LDS row padding in elements.
+template <int WM_, int WN_, int TM_, int TN_, int BK_ = 32, int OCC_ = 2, int EPV_ = 4, int PAD_ = 4> struct TileCfg {
+    static constexpr int WM = WM_, WN = WN_, TMW = TM_, TNW = TN_, BK = BK_, OCC = OCC_, EPV = EPV_;
+    static constexpr int LDT = BK + PAD_;                      // LDS tile row stride (elements)
+    static constexpr int THREADS = WM * WN * 64;
+    static constexpr int BM = WM * TMW * 32, BN = WN * TNW * 32;
+    static constexpr int TPR = BK / EPV;                       // threads per staged row (16 B each)
+    static constexpr int RPP = THREADS / TPR;                  // rows staged per pass
+    static constexpr int PA = BM / RPP, PW = BN / RPP;
+    static constexpr int SLOTS = 256 * OCC * 256 / THREADS;    // resident blocks on the chip
+};

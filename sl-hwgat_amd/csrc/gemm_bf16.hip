@@ -14,6 +14,7 @@
 //                  read of the row-major tile: ds_read_b64_tr_b16 (gfx950 hardware transpose)
 //                  on LDS rows padded to 320 bytes (4 rows of a 4x16 block land in disjoint
 //                  bank quarters -> conflict-free).
+#include <stdlib.h>
 #include "common.h"
 #include "fused_ops.h"
 
@@ -45,23 +46,35 @@ struct NtArgsB {
     uint32_t pro_seed, epi_seed; float pro_p, epi_p;
 };
 
-constexpr int BM = 128, BN = 128, BK = 64, LDT = BK + 8;       // LDS row stride in bf16 elements (144 B)
+// 128x128 tile, 4 waves.  K64: 144-byte LDS rows, 72 KB -> 2 blocks / CU.  K32: 80-byte rows,
+// 40 KB -> 3 blocks / CU (these kernels are latency-bound: more resident blocks = more bytes in flight).
+// 256x256 (8 waves, 64x128 per wave, 1 block / CU): with bf16 MFMA the 128x128 tile is L2-bound
+// (L2->LDS bytes = M*N*K*2*(1/BM + 1/BN), ~6x the HBM bytes at stage 2); 256x256 halves that.
+using NtB64 = TileCfg<2, 2, 2, 2, 64, 2, 8, 8>;
+using NtB32 = TileCfg<2, 2, 2, 2, 32, 3, 8, 8>;
+using NtB256 = TileCfg<4, 2, 2, 4, 64, 1, 8, 8>;
 
-template <int PRO, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_nt_bf16_k(NtArgsB p) {
-    __shared__ __attribute__((aligned(16))) bf16_t sm[2 * 2 * BM * LDT];      // [buf][A|W][128][72]
+// A (tile, K-slab) cursor over the work of one persistent block.
+struct SlabIt {
+    int t, s, n0;
+    int64_t m0;
+    bool valid;
+};
+
+template <int PRO, int EPI, typename C>
+__global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt_bf16_k(NtArgsB p) {
+    constexpr int BM = C::BM, BN = C::BN, BK = C::BK, LDT = C::LDT, PA = C::PA, PW = C::PW, RPP = C::RPP;
+    constexpr int TMW = C::TMW, TNW = C::TNW;
+    __shared__ __attribute__((aligned(16))) bf16_t sm[2 * (BM + BN) * LDT];   // [buf][A rows | W rows][LDT]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane & 31, hh = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / C::WN, wn = wave % C::WN;
     const int tiles_n = p.N / BN;
     const int n_tiles = (int)(p.M / BM) * tiles_n;
     const int n_slab = p.K / BK;
-    const int lrow = tid >> 3, lc8 = (tid & 7) * 8;            // rows lrow + 32*i, bf16 columns lc8..lc8+7
+    const int lrow = tid / C::TPR, lc8 = (tid % C::TPR) * 8;   // rows lrow + RPP*i, bf16 columns lc8..lc8+7
     const uint32_t pro_th = drop_thresh(p.pro_p);
     const float pro_sc = 1.0f / (1.0f - p.pro_p);
-
-    u32x4 ra[4], rw[4];
-    float ln_mean[4], ln_rstd[4];
 
     const int row_blocks = (int)(p.M / BM);
     const int swz_tiles = (row_blocks / 8) * 8 * tiles_n;
@@ -78,39 +91,49 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_k(NtArgsB p) {
         m0 = (int64_t)rb * BM;
         n0 = nt * BN;
     };
-    auto issue = [&](int64_t m0, int n0, int slab, bool new_tile) {
-        const int k0 = slab * BK + lc8;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int64_t row = m0 + lrow + 32 * i;
-            ra[i] = *reinterpret_cast<const u32x4*>(p.A + row * p.K + k0);
-            rw[i] = *reinterpret_cast<const u32x4*>(p.W + (int64_t)(n0 + lrow + 32 * i) * p.K + k0);
-            if constexpr (PRO == PRO_LN) {
-                if (new_tile) { ln_mean[i] = p.mean[row]; ln_rstd[i] = p.rstd[row]; }
-            }
+    auto advance = [&](SlabIt& it) {
+        if (++it.s == n_slab) {
+            it.s = 0;
+            it.t += gridDim.x;
+            it.valid = it.t < n_tiles;
+            if (it.valid) tile_origin(it.t, it.m0, it.n0);
         }
     };
-    auto commit = [&](int buf, int64_t m0, int slab) {
-        bf16_t* As = sm + buf * (2 * BM * LDT);
+    // These kernels are latency-bound (16 MFMAs per slab): the loads of TWO slabs are kept in flight
+    // in two register sets, each committed to LDS one iteration after the other was issued.
+    auto issue = [&](u32x4 (&ra)[PA], u32x4 (&rw)[PW], float (&lm)[PA], float (&lr)[PA], const SlabIt& it) {
+        const int k0 = it.s * BK + lc8;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int64_t row = it.m0 + lrow + RPP * i;
+            ra[i] = *reinterpret_cast<const u32x4*>(p.A + row * p.K + k0);
+            if constexpr (PRO == PRO_LN) { lm[i] = p.mean[row]; lr[i] = p.rstd[row]; }
+        }
+#pragma unroll
+        for (int i = 0; i < PW; ++i)
+            rw[i] = *reinterpret_cast<const u32x4*>(p.W + (int64_t)(it.n0 + lrow + RPP * i) * p.K + k0);
+    };
+    auto commit = [&](u32x4 (&ra)[PA], u32x4 (&rw)[PW], float (&lm)[PA], float (&lr)[PA], const SlabIt& it, int buf) {
+        bf16_t* As = sm + buf * ((BM + BN) * LDT);
         bf16_t* Ws = As + BM * LDT;
-        const int k0 = slab * BK + lc8;
+        const int k0 = it.s * BK + lc8;
         float g[8], b[8];
         if constexpr (PRO == PRO_LN) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) { g[e] = p.gamma[k0 + e]; b[e] = p.beta[k0 + e]; }
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < PA; ++i) {
             u32x4 a = ra[i];
             if constexpr (PRO == PRO_LN) {
                 float v[8];
                 unpack8(a, v);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (v[e] - ln_mean[i]) * ln_rstd[i] * g[e] + b[e];
+                for (int e = 0; e < 8; ++e) v[e] = (v[e] - lm[i]) * lr[i] * g[e] + b[e];
                 a = pack8(v);
             } else if constexpr (PRO == PRO_DROP) {
                 if (pro_th) {
-                    const uint64_t e0 = (uint64_t)(m0 + lrow + 32 * i) * p.K + k0;
+                    const uint64_t e0 = (uint64_t)(it.m0 + lrow + RPP * i) * p.K + k0;
                     const f32x4 k0v = drop_keep4(p.pro_seed, e0, pro_th, pro_sc);
                     const f32x4 k1v = drop_keep4(p.pro_seed, e0 + 4, pro_th, pro_sc);
                     float v[8];
@@ -120,85 +143,67 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_k(NtArgsB p) {
                     a = pack8(v);
                 }
             }
-            *reinterpret_cast<u32x4*>(As + (lrow + 32 * i) * LDT + lc8) = a;
-            *reinterpret_cast<u32x4*>(Ws + (lrow + 32 * i) * LDT + lc8) = rw[i];
+            *reinterpret_cast<u32x4*>(As + (lrow + RPP * i) * LDT + lc8) = a;
         }
+#pragma unroll
+        for (int i = 0; i < PW; ++i) *reinterpret_cast<u32x4*>(Ws + (lrow + RPP * i) * LDT + lc8) = rw[i];
     };
 
-    int t = blockIdx.x;
-    if (t >= n_tiles) return;
-    int64_t m0; int n0;
-    tile_origin(t, m0, n0);
-    issue(m0, n0, 0, true);
-    commit(0, m0, 0);
-    __syncthreads();
-    int buf = 0;
-
-    while (true) {
-        f32x16 acc[2][2];
+    f32x16 acc[TMW][TNW];
+    auto compute = [&](int buf, bool first) {
+        if (first) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TMW; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < TNW; ++j)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-        int tn = t; int64_t mn = m0; int nn = n0;
-        for (int s = 0; s < n_slab; ++s) {
-            bool have_next = true, new_tile = false;
-            int s_next = s + 1;
-            if (s_next == n_slab) {
-                tn = t + gridDim.x;
-                have_next = tn < n_tiles;
-                s_next = 0;
-                new_tile = true;
-                if (have_next) tile_origin(tn, mn, nn);
-            }
-            if (have_next) issue(mn, nn, s_next, new_tile);
-
-            const bf16_t* As = sm + buf * (2 * BM * LDT);
-            const bf16_t* Ws = As + BM * LDT;
-            const bf16_t* ap = As + (wm * 64 + lq) * LDT + 8 * hh;
-            const bf16_t* wp = Ws + (wn * 64 + lq) * LDT + 8 * hh;
-#pragma unroll
-            for (int kk = 0; kk < BK / 16; ++kk) {
-                const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(ap + 16 * kk);
-                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(ap + 32 * LDT + 16 * kk);
-                const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(wp + 16 * kk);
-                const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(wp + 32 * LDT + 16 * kk);
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
-            }
-            if (have_next) commit(buf ^ 1, mn, s_next);
-            __syncthreads();
-            buf ^= 1;
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
         }
-
-        // ---- epilogue through the idle LDS buffer (fp32 staging, [32][68] per wave)
-        {
-            const uint32_t epi_th = drop_thresh(p.epi_p);
-            const float epi_sc = 1.0f / (1.0f - p.epi_p);
-            constexpr int SLD = 68;
-            float* stg = reinterpret_cast<float*>(sm + (buf ^ 1) * (2 * BM * LDT)) + wave * (32 * SLD);
-            const int er = lane >> 4, ec = (lane & 15) * 4;
-            const int col = n0 + wn * 64 + ec;
+        const bf16_t* As = sm + buf * ((BM + BN) * LDT);
+        const bf16_t* Ws = As + BM * LDT;
+        const bf16_t* ap = As + (wm * (TMW * 32) + lq) * LDT + 8 * hh;
+        const bf16_t* wp = Ws + (wn * (TNW * 32) + lq) * LDT + 8 * hh;
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            bf16x8 af[TMW], bfr[TNW];
+#pragma unroll
+            for (int i = 0; i < TMW; ++i) af[i] = *reinterpret_cast<const bf16x8*>(ap + i * 32 * LDT + 16 * kk);
+#pragma unroll
+            for (int j = 0; j < TNW; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(wp + j * 32 * LDT + 16 * kk);
+#pragma unroll
+            for (int i = 0; i < TMW; ++i)
+#pragma unroll
+                for (int j = 0; j < TNW; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    // epilogue through an idle LDS buffer (fp32 staging, 32 x SW per wave), then row-wise 8 B/lane bf16 stores
+    auto epilogue = [&](int64_t m0, int n0, int idle) {
+        const uint32_t epi_th = drop_thresh(p.epi_p);
+        const float epi_sc = 1.0f / (1.0f - p.epi_p);
+        constexpr int SW = ((BM + BN) * LDT * 2 >= (C::THREADS / 64) * 32 * 68 * 4) ? 64 : 32;
+        constexpr int SLD = SW + 4, LPR = SW / 4, RPS = 64 / LPR, NPS = 32 / RPS;
+        float* stg = reinterpret_cast<float*>(sm + idle * ((BM + BN) * LDT)) + wave * (32 * SLD);
+        const int er = lane / LPR, ec = (lane % LPR) * 4;
+#pragma unroll
+        for (int jc = 0; jc < TNW * 32 / SW; ++jc) {
+            const int col = n0 + wn * (TNW * 32) + jc * SW + ec;
             f32x4 bv = {0.f, 0.f, 0.f, 0.f};
             if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_DROP_RES || EPI == EPI_BIAS_GELU_DROP)
                 if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + col);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < TMW; ++i) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < SW / 32; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) stg[crow(r, hh) * SLD + j * 32 + lq] = acc[i][j][r];
+                    for (int r = 0; r < 16; ++r)
+                        stg[crow(r, hh) * SLD + j * 32 + lq] = acc[i][jc * (SW / 32) + j][r];
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll 2
-                for (int ps = 0; ps < 8; ++ps) {
-                    const int rr = ps * 4 + er;
-                    const int64_t off = (m0 + wm * 64 + i * 32 + rr) * p.N + col;
+                for (int ps = 0; ps < NPS; ++ps) {
+                    const int rr = ps * RPS + er;
+                    const int64_t off = (m0 + wm * (TMW * 32) + i * 32 + rr) * p.N + col;
                     f32x4 v = *reinterpret_cast<const f32x4*>(stg + rr * SLD + ec) + bv;
                     f32x4 dk = {1.f, 1.f, 1.f, 1.f};
                     if constexpr (EPI == EPI_BIAS_DROP_RES || EPI == EPI_BIAS_GELU_DROP || EPI == EPI_GELU_BWD) {
@@ -230,10 +235,39 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_k(NtArgsB p) {
                 __builtin_amdgcn_wave_barrier();
             }
         }
+    };
+
+    SlabIt ci{(int)blockIdx.x, 0, 0, 0, true};
+    if (ci.t >= n_tiles) return;
+    tile_origin(ci.t, ci.m0, ci.n0);
+    SlabIt ii = ci, meta0 = ci, meta1 = ci;
+
+    u32x4 ra0[PA], rw0[PW], ra1[PA], rw1[PW];
+    float lm0[PA], lr0[PA], lm1[PA], lr1[PA];
+    bool v0 = false, v1 = false;
+
+    issue(ra0, rw0, lm0, lr0, ii); meta0 = ii; advance(ii);
+    if (ii.valid) { issue(ra1, rw1, lm1, lr1, ii); meta1 = ii; v1 = true; advance(ii); }
+    commit(ra0, rw0, lm0, lr0, meta0, 0);
+    __syncthreads();
+
+    while (true) {
+        // ---- phase A: slab `ci` is in LDS buffer 0, slab ci+1 is in flight in register set 1
+        if (ii.valid) { issue(ra0, rw0, lm0, lr0, ii); meta0 = ii; v0 = true; advance(ii); } else v0 = false;
+        compute(0, ci.s == 0);
+        if (v1) commit(ra1, rw1, lm1, lr1, meta1, 1);
         __syncthreads();
-        t += gridDim.x;
-        if (t >= n_tiles) break;
-        m0 = mn; n0 = nn;
+        if (ci.s == n_slab - 1) { epilogue(ci.m0, ci.n0, 0); __syncthreads(); }
+        advance(ci);
+        if (!ci.valid) break;
+        // ---- phase B: slab `ci` is in LDS buffer 1, slab ci+1 is in flight in register set 0
+        if (ii.valid) { issue(ra1, rw1, lm1, lr1, ii); meta1 = ii; v1 = true; advance(ii); } else v1 = false;
+        compute(1, ci.s == 0);
+        if (v0) commit(ra0, rw0, lm0, lr0, meta0, 0);
+        __syncthreads();
+        if (ci.s == n_slab - 1) { epilogue(ci.m0, ci.n0, 1); __syncthreads(); }
+        advance(ci);
+        if (!ci.valid) break;
     }
 }
 
@@ -388,17 +422,27 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_k(TnArgsB p) {
     }
 }
 
-template <int PRO>
-int launch_nt_b(const NtArgsB& a, int epi, int grid, hipStream_t st) {
+template <int PRO, typename C>
+int launch_nt_b(const NtArgsB& a, int epi, hipStream_t st) {
+    const int64_t tiles = (a.M / C::BM) * (a.N / C::BN);
+    const int grid = (int)(tiles < C::SLOTS ? tiles : C::SLOTS);
     switch (epi) {
-        case EPI_BIAS: gemm_nt_bf16_k<PRO, EPI_BIAS><<<grid, 256, 0, st>>>(a); break;
-        case EPI_BIAS_DROP_RES: gemm_nt_bf16_k<PRO, EPI_BIAS_DROP_RES><<<grid, 256, 0, st>>>(a); break;
-        case EPI_BIAS_GELU_DROP: gemm_nt_bf16_k<PRO, EPI_BIAS_GELU_DROP><<<grid, 256, 0, st>>>(a); break;
-        case EPI_GELU_BWD: gemm_nt_bf16_k<PRO, EPI_GELU_BWD><<<grid, 256, 0, st>>>(a); break;
-        case EPI_NONE: gemm_nt_bf16_k<PRO, EPI_NONE><<<grid, 256, 0, st>>>(a); break;
+        case EPI_BIAS: gemm_nt_bf16_k<PRO, EPI_BIAS, C><<<grid, C::THREADS, 0, st>>>(a); break;
+        case EPI_BIAS_DROP_RES: gemm_nt_bf16_k<PRO, EPI_BIAS_DROP_RES, C><<<grid, C::THREADS, 0, st>>>(a); break;
+        case EPI_BIAS_GELU_DROP: gemm_nt_bf16_k<PRO, EPI_BIAS_GELU_DROP, C><<<grid, C::THREADS, 0, st>>>(a); break;
+        case EPI_GELU_BWD: gemm_nt_bf16_k<PRO, EPI_GELU_BWD, C><<<grid, C::THREADS, 0, st>>>(a); break;
+        case EPI_NONE: gemm_nt_bf16_k<PRO, EPI_NONE, C><<<grid, C::THREADS, 0, st>>>(a); break;
         default: return HWGAT_EINVAL;
     }
     HWGAT_LAUNCH_CHECK();
+}
+
+int bf16_tile_override() {                                      // HWGAT_BF16_TILE=k64|k32 (A/B measurements)
+    static const int v = [] {
+        const char* e = getenv("HWGAT_BF16_TILE");
+        return !e ? 0 : (e[1] == '6' ? 1 : (e[1] == '3' ? 2 : (e[1] == '2' ? 3 : 0)));   // k64 | k32 | k256
+    }();
+    return v;
 }
 
 }  // namespace
@@ -408,7 +452,7 @@ extern "C" int hwgat_linear_nt_bf16(const void* A, const void* W, const float* b
                                     const float* beta, uint32_t pro_seed, float pro_p, int epi, const void* res,
                                     void* C2, const void* aux, uint32_t epi_seed, float epi_p, void* stream) {
     if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) return HWGAT_EINVAL;
-    if (M % BM || N % BN || K % BK || (M / BM) * (int64_t)(N / BN) > 0x7fffffff) return HWGAT_ESHAPE;
+    if (M % 128 || N % 128 || K % 64 || (M / 128) * (int64_t)(N / 128) > 0x7fffffff) return HWGAT_ESHAPE;
     if (pro == PRO_LN && (!mean || !rstd || !gamma || !beta)) return HWGAT_EINVAL;
     if (epi == EPI_BIAS_DROP_RES && !res) return HWGAT_EINVAL;
     if (epi == EPI_BIAS_GELU_DROP && !C2) return HWGAT_EINVAL;
@@ -416,15 +460,18 @@ extern "C" int hwgat_linear_nt_bf16(const void* A, const void* W, const float* b
     if (pro_p < 0.f || pro_p >= 1.f || epi_p < 0.f || epi_p >= 1.f) return HWGAT_EINVAL;
     NtArgsB a{(const bf16_t*)A, (const bf16_t*)W, bias, (bf16_t*)C, (bf16_t*)C2, (const bf16_t*)res,
               (const bf16_t*)aux, mean, rstd, gamma, beta, M, N, K, pro_seed, epi_seed, pro_p, epi_p};
-    const int64_t tiles = (M / BM) * (N / BN);
-    const int grid = (int)(tiles < 512 ? tiles : 512);
     hipStream_t st = (hipStream_t)stream;
+    const bool k32 = bf16_tile_override() == 2;
+    // measured: the 8-wave 256x256 tile is slower here as well (26.4 vs 18.9 ms per step of NT time)
+    const bool big = bf16_tile_override() == 3 && M % 256 == 0 && N % 256 == 0;
+#define NTB_GO(P) return big ? launch_nt_b<P, NtB256>(a, epi, st) : (k32 ? launch_nt_b<P, NtB32>(a, epi, st) : launch_nt_b<P, NtB64>(a, epi, st))
     switch (pro) {
-        case PRO_NONE: return launch_nt_b<PRO_NONE>(a, epi, grid, st);
-        case PRO_LN: return launch_nt_b<PRO_LN>(a, epi, grid, st);
-        case PRO_DROP: return launch_nt_b<PRO_DROP>(a, epi, grid, st);
+        case PRO_NONE: NTB_GO(PRO_NONE);
+        case PRO_LN: NTB_GO(PRO_LN);
+        case PRO_DROP: NTB_GO(PRO_DROP);
         default: return HWGAT_EINVAL;
     }
+#undef NTB_GO
 }
 
 extern "C" int hwgat_linear_tn_bf16(const void* A, const void* B, float* dW, float* db, int64_t M, int N, int K,

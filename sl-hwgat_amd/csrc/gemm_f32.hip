@@ -46,16 +46,6 @@ constexpr int BK_MIN = 16;                                      // K must be a m
 //   NtBig    4x2 waves x (2x4) tiles = 256x256 block, 512 threads, 1 block / CU (still 2 waves / SIMD):
 //            twice the MFMAs per barrier, half the global->LDS bytes per flop, 25 % fewer LDS
 //            fragment reads per MFMA.  Needs M % 256 == N % 256 == 0.
-template <int WM_, int WN_, int TM_, int TN_, int BK_ = 32, int OCC_ = 2> struct TileCfg {
-    static constexpr int WM = WM_, WN = WN_, TMW = TM_, TNW = TN_, BK = BK_, OCC = OCC_;
-    static constexpr int LDT = BK + 4;                         // LDS tile row stride (floats), conflict-free b128 reads
-    static constexpr int THREADS = WM * WN * 64;
-    static constexpr int BM = WM * TMW * 32, BN = WN * TNW * 32;
-    static constexpr int TPR = BK / 4;                         // threads per staged row (16 B each)
-    static constexpr int RPP = THREADS / TPR;                  // rows staged per pass
-    static constexpr int PA = BM / RPP, PW = BN / RPP;
-    static constexpr int SLOTS = 256 * OCC * 256 / THREADS;    // resident blocks on the chip
-};
 using NtSmall = TileCfg<2, 2, 2, 2>;
 using NtBig = TileCfg<4, 2, 2, 4, 32, 1>;
 using NtK16 = TileCfg<2, 2, 2, 2, 16, 3>;                      // 41 KB LDS -> 3 blocks / CU
@@ -260,20 +250,22 @@ struct TnArgs {
     uint32_t pro_seed; float pro_p;
 };
 
-constexpr int TM = 32;                                         // rows of M per LDS stage
+// rows of M per LDS stage = C::BK (32, or 16 for the 3-blocks-per-CU configuration)
 
 // dW tile configurations (output tile BT x BT of dW, both operands [32][BT] per stage):
 //   TnSmall  2x2 waves x (2x2) tiles = 128x128, 256 threads, 2 blocks / CU
 //   TnBig    4x2 waves x (2x4) tiles = 256x256, 512 threads, 1 block / CU (N % 256 == K % 256 == 0)
 using TnSmall = TileCfg<2, 2, 2, 2>;
-using TnBig = TileCfg<4, 2, 2, 4>;
+using TnBig = TileCfg<4, 2, 2, 4, 32, 1>;
+using TnK16 = TileCfg<2, 2, 2, 2, 16, 3>;                      // 32 KB LDS -> 3 blocks / CU
 
 template <int PRO, bool BLN, typename C>
-__global__ __launch_bounds__(C::THREADS, 2) void gemm_tn_k(TnArgs p) {
+__global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_tn_k(TnArgs p) {
+    constexpr int TM = C::BK;
     constexpr int BT = C::BM;                                  // == C::BN
     constexpr int TNW = C::TMW, TKW = C::TNW;
     constexpr int TPR = BT / 4;                                // threads per staged row (16 B each)
-    constexpr int RPP = C::THREADS / TPR;                      // rows per pass (8 in both configs)
+    constexpr int RPP = C::THREADS / TPR;                      // rows per pass (8 in every config)
     constexpr int NP = TM / RPP;                               // passes per operand per stage
     __shared__ __attribute__((aligned(16))) float sm[2 * 2 * TM * BT];       // [buf][A|B][32][BT]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -440,6 +432,7 @@ int tile_override() {
 
 template <int PRO, bool BLN, typename C>
 int launch_tn(TnArgs a, hipStream_t st) {
+    constexpr int TM = C::BK;
     const int n_tiles = (a.N / C::BM) * (a.K / C::BM);
     // Blocks are equal-sized and fill C::SLOTS resident slots, so they execute in rounds: pick the
     // number of M slices so that blocks = n_split * n_tiles is an exact multiple of the slots (no
@@ -480,7 +473,8 @@ extern "C" int hwgat_linear_nt_f32(const float* A, const float* W, const float* 
     // Tile choice, measured on MI355X (profiles/r01f_gemm_tile_ab.txt):
     //  - the 8-wave 256x256 tile loses to two independent 128x128 blocks per CU (110 vs 129 TF at
     //    K=512): kept only behind HWGAT_GEMM_TILE=big for A/B runs;
-    //  - K slabs of 16 with THREE resident blocks per CU are ~1 % slower for plain epilogues but
+    //  - four resident blocks (K16, 128 VGPRs) are 2-3 % slower than two; K slabs of 16 with THREE
+    //    resident blocks per CU are ~1 % slower for plain epilogues but
     //    7-15 % faster when the epilogue is heavy (dropout+residual, GELU, GELU backward): the third
     //    block's MFMAs cover the epilogue's loads/stores.
     const bool heavy = epi == EPI_BIAS_DROP_RES || epi == EPI_BIAS_GELU_DROP || epi == EPI_GELU_BWD;
@@ -501,7 +495,7 @@ extern "C" int hwgat_linear_tn_f32(const float* A, const float* B, float* dW, fl
                                    const float* rstd, const float* gamma, const float* beta, void* stream) {
     if (!A || !B || !dW || M <= 0 || N <= 0 || K <= 0) return HWGAT_EINVAL;
     if (mean && (!rstd || !gamma || !beta)) return HWGAT_EINVAL;
-    if (M % TM || N % 128 || K % 128) return HWGAT_ESHAPE;
+    if (M % 32 || N % 128 || K % 128) return HWGAT_ESHAPE;
     if (pro_p < 0.f || pro_p >= 1.f) return HWGAT_EINVAL;
     TnArgs a{A, B, dW, db, mean, rstd, gamma, beta, M, N, K, 0, 0, pro_seed, pro_p};
     hipStream_t st = (hipStream_t)stream;
@@ -509,7 +503,8 @@ extern "C" int hwgat_linear_tn_f32(const float* A, const float* B, float* dW, fl
     bool big = (N % 256 == 0) && (K % 256 == 0) && (int64_t)N * K >= 512 * 1024;
     if (tile_override() == 1) big = false;
     if (tile_override() == 2) big = (N % 256 == 0) && (K % 256 == 0);
-#define TN_GO(P, L) return big ? launch_tn<P, L, TnBig>(a, st) : launch_tn<P, L, TnSmall>(a, st)
+    const bool k16 = tile_override() == 3;
+#define TN_GO(P, L) return big ? launch_tn<P, L, TnBig>(a, st) : (k16 ? launch_tn<P, L, TnK16>(a, st) : launch_tn<P, L, TnSmall>(a, st))
     if (pro_p > 0.f) { if (mean) TN_GO(PRO_DROP, true); else TN_GO(PRO_DROP, false); }
     if (mean) TN_GO(PRO_NONE, true);
     TN_GO(PRO_NONE, false);
