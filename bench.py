@@ -179,6 +179,20 @@ def main():
                     kern[name]["traffic"] = pmc[name]["traffic_bytes_per_launch"]
         except (OSError, KeyError):
             pass
+        # linears: useful flops per step (fwd + dX + dW = 3 x 16*E*d_i per block) against the dense MFMA peak
+        sum_d = sum(dep * c["d0"] * 2 ** i for i, dep in enumerate((2, 2, 4)))
+        n_micro = -(-c["B"] // b_launch)
+        flops_fwd = 16.0 * E * sum_d * n_micro                        # per step, forward linears
+        peak = F32_MFMA_PEAK if args.dtype == "f32" else 2.5e15
+        for name, fl in (("hwgat_linear_nt_" + args.dtype.replace("f32", "f32"), 2 * flops_fwd),
+                         ("hwgat_linear_tn_" + args.dtype.replace("f32", "f32"), flops_fwd)):
+            n, ms = timers.get(name, (0, 0.0))
+            if n:
+                ach = fl * args.steps / (ms * 1e-3)
+                kern[name] = {"bound": "mfma", "achieved": round(ach / 1e12, 1), "peak": peak / 1e12,
+                              "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                              "launches": n, "ms_per_step": round(ms / args.steps, 3),
+                              "flops_per_step": fl}
         others = {k: {"launches": v[0], "total_ms": round(v[1], 3)} for k, v in timers.items()
                   if k not in kern}
         hip_ms = sum(v[1] for v in timers.values())

@@ -73,3 +73,59 @@ def test_part_tables():
         t = hw.part_table(J).numpy()
         assert t.shape == (nW * 16,) and t.min() >= 0 and t.max() < J
         assert all((t[w * 16:w * 16 + 3] == [0, 1, 2]).all() for w in range(nW))
+
+
+def test_c_abi_rejects_bad_arguments_without_launching():
+    """argument validation happens before any HIP call, so it is testable without a GPU"""
+    L = hw._lib.lib()
+    import ctypes
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    assert L.hwgat_win_attn_fwd(None, p, p, None, 1, 4, 1, 2, 64, 0, 0, None) == -1          # HWGAT_EINVAL
+    assert L.hwgat_win_attn_fwd(p, p, p, None, 1, 3, 1, 2, 64, 0, 0, None) == -2             # odd F: HWGAT_ESHAPE
+    assert L.hwgat_win_attn_fwd(p, p, p, None, 1, 4, 1, 2, 48, 0, 0, None) == -2             # head_dim 48
+    assert L.hwgat_win_attn_bwd(p, p, p, p, None, 1, 4, 1, 2, 64, 0, 7, None) == -3          # HWGAT_EDTYPE
+    assert L.hwgat_ln_fwd(p, p, p, p, p, p, 8, 100, 0, None) == -2                           # width 100
+    assert L.hwgat_linear_nt_f32(p, p, None, p, 100, 128, 128, 0, None, None, None, None, 0, 0.0, 0,
+                                 None, None, None, 0, 0.0, None) == -2                        # M % 128
+    assert L.hwgat_linear_nt_f32(p, p, None, p, 128, 128, 128, 1, None, None, None, None, 0, 0.0, 0,
+                                 None, None, None, 0, 0.0, None) == -1                        # LN prologue w/o stats
+    assert L.hwgat_linear_nt_f32(p, p, None, p, 128, 128, 128, 0, None, None, None, None, 0, 0.0, 1,
+                                 None, None, None, 0, 1.5, None) == -1                        # residual missing / p >= 1
+    assert L.hwgat_linear_tn_f32(p, p, p, None, 64, 128, 100, 0, 0.0, None, None, None, None, None) == -2
+    assert L.hwgat_embed_fwd(p, None, p, None, p, 1, 4, 29, 64, 2, 128, 0, 0, 0.0, None) == -2   # J != K without a table
+    assert L.hwgat_merge(p, p, 1, 3, 16, 128, 0, 0, None) == -2
+
+
+@pytest.mark.skipif(not __import__("os").path.exists("/root/reference/hwgat/models/HWGATE.py"),
+                    reason="reference tree only exists in the development container")
+def test_checkpoint_interchange_with_the_reference_class():
+    """state_dict of this backend loads STRICTLY into the reference Model and vice versa
+    (SURVEY 8b / 8f-4).  Development container only; nothing here runs on the GPU box."""
+    import sys, types
+    for name in ("timm", "timm.models", "timm.models.layers"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["timm.models.layers"].trunc_normal_ = torch.nn.init.trunc_normal_   # init-only import, HWGATE.py:4
+    sys.path.insert(0, "/root/reference/hwgat")
+    try:
+        ref_mod = importlib.import_module("models.HWGATE")
+        ref_par = importlib.import_module("models.model_params")
+    finally:
+        sys.path.remove("/root/reference/hwgat")
+    rp = ref_par.HWGATEParams({"src_len": 64, "num_class": 11}, 2, torch.device("cpu"))
+    ref = ref_mod.Model(*rp.get_model_params())
+    hp = hw.HWGATEParams({"src_len": 64, "num_class": 11}, 2, torch.device("cpu"))
+    assert [type(a) for a in hp.get_model_params()] == [type(a) for a in rp.get_model_params()]
+    assert torch.equal(hp.adj_mat, rp.adj_mat)
+    mine = hw.Model(*hp.get_model_params())
+    sd_ref, sd_mine = ref.state_dict(), mine.state_dict()
+    assert list(sd_ref.keys()) == list(sd_mine.keys())                       # same keys, same order
+    assert all(sd_ref[k].shape == sd_mine[k].shape and sd_ref[k].dtype == sd_mine[k].dtype for k in sd_ref)
+    mine.load_state_dict(sd_ref, strict=True)
+    ref.load_state_dict(sd_mine, strict=True)
+    for k in sd_ref:
+        if k.endswith("attn_mask") or k == "pos_encoder.pe":
+            assert torch.equal(sd_ref[k], sd_mine[k]), k                      # derived buffers are identical
+    assert not mine.B.requires_grad and not ref.B.requires_grad
+    assert sum(p.numel() for p in mine.parameters() if p.requires_grad) == \
+        sum(p.numel() for p in ref.parameters() if p.requires_grad)
