@@ -53,6 +53,17 @@ def test_three_adamw_steps_match_the_oracle():
         assert abs(a - b) < 2e-4, (losses, ref_losses)
     assert ref_losses[0] != ref_losses[-1]                     # the trajectory actually moved
     sd = model.state_dict()
-    worst = max(rel_err(sd[k].cpu(), v.detach()) for k, v in ref_p.items() if v.requires_grad)
-    print("losses", losses, "ref", ref_losses, "worst param rel err", worst)
-    assert worst < 2e-4
+    errs = {}
+    for k, v in ref_p.items():
+        if not v.requires_grad:
+            continue
+        a, b = sd[k].cpu(), v.detach()
+        if k.endswith("attn.qkv.bias"):
+            # the key bias has an exactly-zero true gradient (softmax is invariant to it), so both sides feed
+            # rounding noise to Adam, which turns it into +-lr updates: compare only the q and v thirds
+            d = a.numel() // 3
+            a, b = torch.cat([a[:d], a[2 * d:]]), torch.cat([b[:d], b[2 * d:]])
+        errs[k] = rel_err(a, b)
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:3]
+    print("losses", losses, "ref", ref_losses, "worst param rel errs", worst)
+    assert worst[0][1] < 2e-4
