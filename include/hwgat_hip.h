@@ -43,6 +43,10 @@ int hwgat_abi_version(void);
  * = D tile of A(32x2) . B(2x32) with A[i][k] = a[i*2+k], B[k][j] = b[k*32+j]. */
 int hwgat_debug_mfma32x32x2(const float* a, const float* b, float* out, void* stream);
 
+/* ---- debug: register-only loop of `iters` x 4 x n_acc v_mfma_f32_32x32x2_f32 per wave (n_acc in
+ * {4,16} independent accumulators, `blocks` x 4 waves): the attainable fp32 MFMA rate of the part. */
+int hwgat_debug_mfma_peak(float* out, int blocks, int iters, int n_acc, void* stream);
+
 /* ---- a-2/a-3/a-12: part gather + Fourier features + positional encoding.
  * Replaces WindowCreate (dataTransform.py:445-455), the Fourier mapping
  * (HWGATE.py:343-345) and PositionalEncoding's add (HWGATE.py:25-27).

@@ -23,6 +23,7 @@ _U, _F = ctypes.c_uint32, ctypes.c_float
 _SIGS = {
     "hwgat_abi_version": [],
     "hwgat_debug_mfma32x32x2": [_P, _P, _P, _P],
+    "hwgat_debug_mfma_peak": [_P, _I, _I, _I, _P],
     "hwgat_embed_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _U, _F, _P],
     "hwgat_ln_fwd": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
     "hwgat_ln_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],

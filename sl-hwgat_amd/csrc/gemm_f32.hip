@@ -26,18 +26,12 @@
 // Dropout masks are a counter-based hash of (seed, element index): nothing is stored,
 // backward regenerates the mask.
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 #include "fused_ops.h"
+#include "gemm_f32.h"
 
 namespace {
-
-struct NtArgs {
-    const float* A; const float* W; const float* bias; float* C;
-    float* C2; const float* res; const float* aux;
-    const float* mean; const float* rstd; const float* gamma; const float* beta;
-    int64_t M; int N, K;
-    uint32_t pro_seed, epi_seed; float pro_p, epi_p;
-};
 
 constexpr int BK_MIN = 16;                                      // K must be a multiple of the slab depth
 
@@ -259,15 +253,20 @@ using TnSmall = TileCfg<2, 2, 2, 2>;
 using TnBig = TileCfg<4, 2, 2, 4, 32, 1>;
 using TnK16 = TileCfg<2, 2, 2, 2, 16, 3>;                      // 32 KB LDS -> 3 blocks / CU
 
-template <int PRO, bool BLN, typename C>
+// MF16 selects v_mfma_f32_16x16x4_f32 (the form the vendor library uses: same flop rate, half the
+// accumulator-register traffic per flop) instead of v_mfma_f32_32x32x2_f32.  Measured on MI355X:
+// +2..4 % at K <= 256, -2 % at K = 512 -- not the source of the library's 0.91 vs our 0.82 MFMA
+// utilisation; kept behind HWGAT_GEMM_TILE=m for A/B runs.
+template <int PRO, bool BLN, typename C, bool MF16 = false>
 __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_tn_k(TnArgs p) {
     constexpr int TM = C::BK;
     constexpr int BT = C::BM;                                  // == C::BN
+    constexpr int LDR = MF16 ? BT + 16 : BT;                   // LDS row stride: +16 keeps the 4 rows of a 16x16x4 operand on distinct banks
     constexpr int TNW = C::TMW, TKW = C::TNW;
     constexpr int TPR = BT / 4;                                // threads per staged row (16 B each)
     constexpr int RPP = C::THREADS / TPR;                      // rows per pass (8 in every config)
     constexpr int NP = TM / RPP;                               // passes per operand per stage
-    __shared__ __attribute__((aligned(16))) float sm[2 * 2 * TM * BT];       // [buf][A|B][32][BT]
+    __shared__ __attribute__((aligned(16))) float sm[2 * 2 * TM * LDR];      // [buf][A|B][TM][LDR]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane & 31, hh = lane >> 5;
     const int wn = wave / C::WN, wk = wave % C::WN;
@@ -306,8 +305,8 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_tn
         }
     };
     auto commit = [&](int buf, int it) {
-        float* As = sm + buf * (2 * TM * BT);
-        float* Bs = As + TM * BT;
+        float* As = sm + buf * (2 * TM * LDR);
+        float* Bs = As + TM * LDR;
         const int64_t r0 = r_begin + (int64_t)it * TM + lrow;
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
@@ -316,40 +315,47 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_tn
                 a *= drop_keep4(p.pro_seed, (uint64_t)(r0 + RPP * i) * p.N + n0 + lc4, pro_th, pro_sc);
             if constexpr (BLN) b = (b - bm[i]) * bs[i] * lg + lb;
             colsum += a;
-            *reinterpret_cast<f32x4*>(As + (lrow + RPP * i) * BT + lc4) = a;
-            *reinterpret_cast<f32x4*>(Bs + (lrow + RPP * i) * BT + lc4) = b;
+            *reinterpret_cast<f32x4*>(As + (lrow + RPP * i) * LDR + lc4) = a;
+            *reinterpret_cast<f32x4*>(Bs + (lrow + RPP * i) * LDR + lc4) = b;
         }
     };
 
-    f32x16 acc[TNW][TKW];
+    // accumulators: 32x32 tiles (f32x16) or 16x16 tiles (f32x4), 64 registers per lane either way
+    constexpr int TI = MF16 ? TNW * 2 : TNW, TJ = MF16 ? TKW * 2 : TKW, TS = MF16 ? 16 : 32;
+    typedef typename std::conditional<MF16, f32x4, f32x16>::type acc_t;
+    acc_t acc[TI][TJ];
 #pragma unroll
-    for (int i = 0; i < TNW; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int jj = 0; jj < TKW; ++jj)
+        for (int jj = 0; jj < TJ; ++jj)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][jj][e] = 0.f;
+            for (int e = 0; e < (MF16 ? 4 : 16); ++e) acc[i][jj][e] = 0.f;
 
     issue(0);
     commit(0, 0);
     __syncthreads();
     int buf = 0;
+    // operand lane maps: 32x32x2: lane (col = lane&31, k = lane>>5), 2 rows of m per step;
+    //                    16x16x4: lane (col = lane&15, k = lane>>4), 4 rows of m per step
+    const int lc = MF16 ? (lane & 15) : lq, lk = MF16 ? (lane >> 4) : hh;
+    constexpr int KPS = MF16 ? 4 : 2;                          // rows of m consumed per MFMA step
     for (int it = 0; it < n_it; ++it) {
         const bool have_next = it + 1 < n_it;
         if (have_next) issue(it + 1);
-        const float* As = sm + buf * (2 * TM * BT) + wn * (TNW * 32) + lq;
-        const float* Bs = sm + buf * (2 * TM * BT) + TM * BT + wk * (TKW * 32) + lq;
+        const float* As = sm + buf * (2 * TM * LDR) + wn * (TNW * 32) + lc;
+        const float* Bs = sm + buf * (2 * TM * LDR) + TM * LDR + wk * (TKW * 32) + lc;
         // software-pipelined operand fetch: the LDS reads of chunk c+1 are in flight while the
         // MFMAs of chunk c issue (the compiler then waits with counted lgkmcnt, not 0)
-        constexpr int CH = 4, NCH = TM / 2 / CH;
-        float fa[2][CH][TNW], fb[2][CH][TKW];
+        constexpr int NSTEP = TM / KPS, CH = MF16 ? 2 : 4, NCH = NSTEP / CH;
+        float fa[2][CH][TI], fb[2][CH][TJ];
         auto fetch = [&](int c, int slot) {
 #pragma unroll
             for (int e = 0; e < CH; ++e) {
-                const int ro = (2 * (c * CH + e) + hh) * BT;
+                const int ro = (KPS * (c * CH + e) + lk) * LDR;
 #pragma unroll
-                for (int i = 0; i < TNW; ++i) fa[slot][e][i] = As[ro + 32 * i];
+                for (int i = 0; i < TI; ++i) fa[slot][e][i] = As[ro + TS * i];
 #pragma unroll
-                for (int jj = 0; jj < TKW; ++jj) fb[slot][e][jj] = Bs[ro + 32 * jj];
+                for (int jj = 0; jj < TJ; ++jj) fb[slot][e][jj] = Bs[ro + TS * jj];
             }
         };
         fetch(0, 0);
@@ -360,25 +366,30 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_tn
 #pragma unroll
             for (int e = 0; e < CH; ++e)
 #pragma unroll
-                for (int i = 0; i < TNW; ++i)
+                for (int i = 0; i < TI; ++i)
 #pragma unroll
-                    for (int jj = 0; jj < TKW; ++jj)
-                        acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c & 1][e][i], fb[c & 1][e][jj], acc[i][jj], 0, 0, 0);
+                    for (int jj = 0; jj < TJ; ++jj) {
+                        if constexpr (MF16)
+                            acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[c & 1][e][i], fb[c & 1][e][jj], acc[i][jj], 0, 0, 0);
+                        else
+                            acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c & 1][e][i], fb[c & 1][e][jj], acc[i][jj], 0, 0, 0);
+                    }
             __builtin_amdgcn_sched_barrier(0);
         }
         if (have_next) commit(buf ^ 1, it + 1);
         __syncthreads();
         buf ^= 1;
     }
-    // D[i = n][j = k]: lane (k = lq, hh), reg r -> dW[n = crow(r,hh)][k]
+    // D[i = n][j = k]: 32x32: lane (k = lq, hh), reg r -> dW[n = crow(r,hh)][k]
+    //                  16x16: lane (k = lane&15, q = lane>>4), reg r -> dW[n = 4q + r][k]
 #pragma unroll
-    for (int i = 0; i < TNW; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int jj = 0; jj < TKW; ++jj)
+        for (int jj = 0; jj < TJ; ++jj)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int n = n0 + wn * (TNW * 32) + i * 32 + crow(r, hh);
-                const int k = k0 + wk * (TKW * 32) + jj * 32 + lq;
+            for (int r = 0; r < (MF16 ? 4 : 16); ++r) {
+                const int n = n0 + wn * (TNW * 32) + i * TS + (MF16 ? 4 * lk + r : crow(r, hh));
+                const int k = k0 + wk * (TKW * 32) + jj * TS + lc;
                 atomicAdd(p.dW + (int64_t)n * p.K + k, acc[i][jj][r]);
             }
     if (p.db != nullptr && k0 == 0) {                           // one k-tile column owns the bias gradient
@@ -425,12 +436,12 @@ int launch_nt(const NtArgs& a, int epi, hipStream_t st) {
 int tile_override() {
     static const int v = [] {
         const char* e = getenv("HWGAT_GEMM_TILE");
-        return !e ? 0 : (e[0] == 's' ? 1 : (e[0] == 'b' ? 2 : (e[0] == 'k' ? 3 : 0)));
+        return !e ? 0 : (e[0] == 's' ? 1 : (e[0] == 'b' ? 2 : (e[0] == 'k' ? 3 : (e[0] == 'm' ? 6 : 0))));
     }();
     return v;
 }
 
-template <int PRO, bool BLN, typename C>
+template <int PRO, bool BLN, typename C, bool MF16 = false>
 int launch_tn(TnArgs a, hipStream_t st) {
     constexpr int TM = C::BK;
     const int n_tiles = (a.N / C::BM) * (a.K / C::BM);
@@ -450,7 +461,7 @@ int launch_tn(TnArgs a, hipStream_t st) {
     a.n_split = (int)((a.M + rows - 1) / rows);
     a.rows_per_split = rows;
     const int grid = ((a.n_split + 7) / 8) * 8 * n_tiles;
-    gemm_tn_k<PRO, BLN, C><<<grid, C::THREADS, 0, st>>>(a);
+    gemm_tn_k<PRO, BLN, C, MF16><<<grid, C::THREADS, 0, st>>>(a);
     HWGAT_LAUNCH_CHECK();
 }
 
@@ -504,7 +515,8 @@ extern "C" int hwgat_linear_tn_f32(const float* A, const float* B, float* dW, fl
     if (tile_override() == 1) big = false;
     if (tile_override() == 2) big = (N % 256 == 0) && (K % 256 == 0);
     const bool k16 = tile_override() == 3;
-#define TN_GO(P, L) return big ? launch_tn<P, L, TnBig>(a, st) : (k16 ? launch_tn<P, L, TnK16>(a, st) : launch_tn<P, L, TnSmall>(a, st))
+    const bool mf16 = tile_override() == 6;
+#define TN_GO(P, L) return mf16 ? launch_tn<P, L, TnSmall, true>(a, st) : (big ? launch_tn<P, L, TnBig>(a, st) : (k16 ? launch_tn<P, L, TnK16>(a, st) : launch_tn<P, L, TnSmall>(a, st)))
     if (pro_p > 0.f) { if (mean) TN_GO(PRO_DROP, true); else TN_GO(PRO_DROP, false); }
     if (mean) TN_GO(PRO_NONE, true);
     TN_GO(PRO_NONE, false);

@@ -434,6 +434,53 @@ __global__ void mfma_probe_k(const float* a, const float* b, float* out) {
     for (int i = 0; i < 16; ++i) out[lane * 16 + i] = acc[i];
 }
 
+// register-only MFMA loop: the attainable v_mfma_f32_32x32x2_f32 rate on this part / clock
+template <int NACC>
+__global__ __launch_bounds__(256) void mfma_peak_k(float* out, int iters, float seed) {
+    f32x16 acc[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[a][i] = 0.f;
+    float x = seed + threadIdx.x * 1e-3f, y = seed * 0.5f + threadIdx.x * 2e-3f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int a = 0; a < NACC; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, acc[a], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += acc[a][i];
+    if (s == 12345.678f) out[threadIdx.x] = s;                  // keep the chain alive
+}
+
+// the same with v_mfma_f32_16x16x4_f32 (4 accumulator registers per tile): 4*NACC independent tiles
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+template <int NACC>
+__global__ __launch_bounds__(256) void mfma_peak16_k(float* out, int iters, float seed) {
+    f32x4v acc[4 * NACC];
+#pragma unroll
+    for (int a = 0; a < 4 * NACC; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[a][i] = 0.f;
+    float x = seed + threadIdx.x * 1e-3f, y = seed * 0.5f + threadIdx.x * 2e-3f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r)                              // 2 x (4*NACC) x 2048 flop = 4 x NACC x 4096 flop
+#pragma unroll
+            for (int a = 0; a < 4 * NACC; ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, acc[a], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4 * NACC; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s += acc[a][i];
+    if (s == 12345.678f) out[threadIdx.x] = s;
+}
+
 bool geom_ok(int B, int F, int nW, int nH, int hd) {
     return B > 0 && F > 0 && (F % 2) == 0 && nW > 0 && nH > 0 && (hd == 32 || hd == 64 || hd == 128);
 }
@@ -465,6 +512,16 @@ int launch_bwd(const void* qkv, const void* dO, void* dqkv, const uint32_t* mb, 
 extern "C" int hwgat_debug_mfma32x32x2(const float* a, const float* b, float* out, void* stream) {
     if (!a || !b || !out) return HWGAT_EINVAL;
     mfma_probe_k<<<1, 64, 0, (hipStream_t)stream>>>(a, b, out);
+    HWGAT_LAUNCH_CHECK();
+}
+
+extern "C" int hwgat_debug_mfma_peak(float* out, int blocks, int iters, int n_acc, void* stream) {
+    if (!out || blocks <= 0 || iters <= 0) return HWGAT_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (n_acc == 4) mfma_peak_k<4><<<blocks, 256, 0, st>>>(out, iters, 1.0f);
+    else if (n_acc == 16) mfma_peak_k<16><<<blocks, 256, 0, st>>>(out, iters, 1.0f);
+    else if (n_acc == -4) mfma_peak16_k<4><<<blocks, 256, 0, st>>>(out, iters, 1.0f);      // 16x16x4 form
+    else return HWGAT_ESHAPE;
     HWGAT_LAUNCH_CHECK();
 }
 
