@@ -265,3 +265,40 @@ def test_pinned_batcher_feeds_raw_joints_through_device_gather():
         assert rel_err(b.cpu(), a.cpu()) < 1e-5
         seen += n
     assert seen == 10
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_wide_config_fully_fused_vs_oracle(dtype):
+    """config-5-like widths (d0=256: stages 256/512/1024, head_dim 128, C=3, nW=7) at a size where every
+    block runs the fused hand-written linears (token counts are multiples of 128 at all three stages):
+    logits and a few gradients vs the fp64 oracle, eval mode and train mode with thresholds."""
+    if not FUSED:
+        pytest.skip("covered by the fused run")
+    T, nW, C, nc, B = 16, 7, 3, 9, 2
+    cfg = dict(kp_dim=C, temporal_dim=T, num_classes=nc, embed_dim=256, num_kps=nW * 16)
+    params = O.synth_params(41, weight_std=0.05, **cfg)
+    hp = hw.HWGATEParams({"src_len": T, "num_class": nc}, C, DEV, num_kps=nW * 16, embed_dim=256)
+    hp.drop_rate = 0.0
+    model = hw.Model(*hp.get_model_params())
+    model.load_state_dict(params, strict=False)
+    model.set_activation_dtype(dtype)
+    assert (B * T // 4 * nW * 16) % 128 == 0
+    g = torch.Generator().manual_seed(8)
+    x = torch.rand(B, T, nW * 16, C, generator=g)
+    y = torch.randint(0, nc, (B,), generator=g)
+    tol = 1e-3 if dtype == torch.float32 else 3e-2
+    for thr in (None, [0.3, 0.1, 0.5, 0.2, 0.07, 0.4, 0.25, 0.6]):
+        ref_p = {k: v.double().requires_grad_(k not in ("B", "pos_encoder.pe")) for k, v in params.items()}
+        oracle = O.OracleHWGAT(ref_p, num_kps=nW * 16, temporal_dim=T, adj=O.window_adjacency(nW))
+        ref = oracle.forward(x.double(), thresholds=thr)
+        O.smoothed_cross_entropy(ref, y).backward()
+        model.train(thr is not None)
+        model.threshold_override = thr
+        model.zero_grad()
+        out = model(x.to(DEV))
+        O.smoothed_cross_entropy(out.float(), y.to(DEV)).backward()
+        assert rel_err(out.float().detach().cpu(), ref.detach()) < tol, (dtype, thr is not None)
+        if dtype == torch.float32 or thr is None:      # under bf16 the threshold selector may flip near ties
+            for name in ("layers.2.blocks.3.ff.fc2.weight", "layers.1.blocks.1.attn.qkv.weight", "layers.0.blocks.0.norm1.weight", "head.weight"):
+                got = dict(model.named_parameters())[name].grad.double().cpu()
+                assert rel_err(got, ref_p[name].grad) < (2e-3 if dtype == torch.float32 else 8e-2), name
