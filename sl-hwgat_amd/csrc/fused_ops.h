@@ -63,7 +63,7 @@ __device__ __forceinline__ float gelu_grad(float x) {
 }
 
 // Tiling configuration of the linear kernels: WM x WN waves, each owning TM x TN MFMA tiles of
-// 32x32; BK = K-slab depth in elements; OCC = resident blocks per CU the launch bounds ask for;
+// 32x32; BK = K-slab depth in elements; OCC = resident blocks (of THREADS threads) per CU;
 // EPV = elements per 16-byte staging vector (4 fp32, 8 bf16); PAD = LDS row padding in elements.
 template <int WM_, int WN_, int TM_, int TN_, int BK_ = 32, int OCC_ = 2, int EPV_ = 4, int PAD_ = 4> struct TileCfg {
     static constexpr int WM = WM_, WN = WN_, TMW = TM_, TNW = TN_, BK = BK_, OCC = OCC_, EPV = EPV_;
@@ -73,5 +73,5 @@ template <int WM_, int WN_, int TM_, int TN_, int BK_ = 32, int OCC_ = 2, int EP
     static constexpr int TPR = BK / EPV;                       // threads per staged row (16 B each)
     static constexpr int RPP = THREADS / TPR;                  // rows staged per pass
     static constexpr int PA = BM / RPP, PW = BN / RPP;
-    static constexpr int SLOTS = 256 * OCC * 256 / THREADS;    // resident blocks on the chip
+    static constexpr int SLOTS = 256 * OCC;                    // resident blocks on the chip (256 CUs)
 };

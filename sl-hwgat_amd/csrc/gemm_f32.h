@@ -11,3 +11,16 @@ struct NtArgs {
 };
 
 
+
+struct TnArgs {
+    const float* A; const float* B; float* dW; float* db;
+    const float* mean; const float* rstd; const float* gamma; const float* beta;
+    int64_t M; int N, K;
+    int n_split; int64_t rows_per_split;
+    uint32_t pro_seed; float pro_p;
+};
+
+
+// 256x256 dW tile, 4 waves x (128x128), one wave per SIMD, pinned MFMA/memory interleave (gemm_f32_tn256.hip);
+// needs N % 256 == K % 256 == 0; fills in n_split / rows_per_split itself
+int hwgat_launch_tn256(TnArgs a, hipStream_t st);

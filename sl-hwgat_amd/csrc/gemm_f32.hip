@@ -236,14 +236,6 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt
 }
 
 // ------------------------------------------------------------------ dW / db
-struct TnArgs {
-    const float* A; const float* B; float* dW; float* db;
-    const float* mean; const float* rstd; const float* gamma; const float* beta;
-    int64_t M; int N, K;
-    int n_split; int64_t rows_per_split;
-    uint32_t pro_seed; float pro_p;
-};
-
 // rows of M per LDS stage = C::BK (32, or 16 for the 3-blocks-per-CU configuration)
 
 // dW tile configurations (output tile BT x BT of dW, both operands [32][BT] per stage):
@@ -436,7 +428,7 @@ int launch_nt(const NtArgs& a, int epi, hipStream_t st) {
 int tile_override() {
     static const int v = [] {
         const char* e = getenv("HWGAT_GEMM_TILE");
-        return !e ? 0 : (e[0] == 's' ? 1 : (e[0] == 'b' ? 2 : (e[0] == 'k' ? 3 : (e[0] == 'm' ? 6 : 0))));
+        return !e ? 0 : (e[0] == 's' ? 1 : (e[0] == 'b' ? 2 : (e[0] == 'k' ? 3 : (e[0] == 'm' ? 6 : (e[0] == 't' ? 7 : 0)))));
     }();
     return v;
 }
@@ -510,12 +502,16 @@ extern "C" int hwgat_linear_tn_f32(const float* A, const float* B, float* dW, fl
     if (pro_p < 0.f || pro_p >= 1.f) return HWGAT_EINVAL;
     TnArgs a{A, B, dW, db, mean, rstd, gamma, beta, M, N, K, 0, 0, pro_seed, pro_p};
     hipStream_t st = (hipStream_t)stream;
-    // measured: the 256x256 dW tile wins (+3 %) only on the largest outputs (>= 512x1024), loses on 256-wide ones
-    bool big = (N % 256 == 0) && (K % 256 == 0) && (int64_t)N * K >= 512 * 1024;
-    if (tile_override() == 1) big = false;
-    if (tile_override() == 2) big = (N % 256 == 0) && (K % 256 == 0);
-    const bool k16 = tile_override() == 3;
-    const bool mf16 = tile_override() == 6;
+    // 256-aligned multi-tile outputs: the one-wave-per-SIMD 256x256 kernel with pinned MFMA/memory
+    // interleave (gemm_f32_tn256.hip; +2..8 % over the variants below, e.g. 131 vs 121-126 TF on
+    // 1536x512).  Single 256x256 outputs and everything else: 128x128 blocks, two per CU.
+    // HWGAT_GEMM_TILE = small | big | k16 | m(fma16) select the alternatives for A/B runs.
+    const int ov = tile_override();
+    if ((ov == 0 || ov == 7) && N % 256 == 0 && K % 256 == 0 && (int64_t)N * K > 256 * 256 && !(pro_p > 0.f && mean))
+        return hwgat_launch_tn256(a, st);
+    const bool big = ov == 2 && (N % 256 == 0) && (K % 256 == 0);
+    const bool k16 = ov == 3;
+    const bool mf16 = ov == 6;
 #define TN_GO(P, L) return mf16 ? launch_tn<P, L, TnSmall, true>(a, st) : (big ? launch_tn<P, L, TnBig>(a, st) : (k16 ? launch_tn<P, L, TnK16>(a, st) : launch_tn<P, L, TnSmall>(a, st)))
     if (pro_p > 0.f) { if (mean) TN_GO(PRO_DROP, true); else TN_GO(PRO_DROP, false); }
     if (mean) TN_GO(PRO_NONE, true);
