@@ -14,7 +14,6 @@
 //                  read of the row-major tile: ds_read_b64_tr_b16 (gfx950 hardware transpose)
 //                  on LDS rows padded to 320 bytes (4 rows of a 4x16 block land in disjoint
 //                  bank quarters -> conflict-free).
-#include <stdlib.h>
 #include "common.h"
 #include "fused_ops.h"
 
@@ -46,13 +45,11 @@ struct NtArgsB {
     uint32_t pro_seed, epi_seed; float pro_p, epi_p;
 };
 
-// 128x128 tile, 4 waves.  K64: 144-byte LDS rows, 72 KB -> 2 blocks / CU.  K32: 80-byte rows,
-// 40 KB -> 3 blocks / CU (these kernels are latency-bound: more resident blocks = more bytes in flight).
-// 256x256 (8 waves, 64x128 per wave, 1 block / CU): with bf16 MFMA the 128x128 tile is L2-bound
-// (L2->LDS bytes = M*N*K*2*(1/BM + 1/BN), ~6x the HBM bytes at stage 2); 256x256 halves that.
+// 128x128 tile, 4 waves, K slabs of 64 (144-byte LDS rows), 72 KB -> 2 blocks / CU.
+// Measured alternatives (all slower or neutral on MI355X, config 3; NT time per step):
+//   K32 x 3 blocks/CU 19.8 ms (vs 20.2) | two-slab register prefetch ring: neutral | 8-wave 256x256: 26.4 ms
+//   | 128x256 (64x128 wave tiles, 2 blocks/CU): 22.0 ms (vs 18.9).
 using NtB64 = TileCfg<2, 2, 2, 2, 64, 2, 8, 8>;
-using NtB32 = TileCfg<2, 2, 2, 2, 32, 3, 8, 8>;
-using NtB256 = TileCfg<4, 2, 2, 4, 64, 1, 8, 8>;
 
 // A (tile, K-slab) cursor over the work of one persistent block.
 struct SlabIt {
@@ -437,14 +434,6 @@ int launch_nt_b(const NtArgsB& a, int epi, hipStream_t st) {
     HWGAT_LAUNCH_CHECK();
 }
 
-int bf16_tile_override() {                                      // HWGAT_BF16_TILE=k64|k32 (A/B measurements)
-    static const int v = [] {
-        const char* e = getenv("HWGAT_BF16_TILE");
-        return !e ? 0 : (e[1] == '6' ? 1 : (e[1] == '3' ? 2 : (e[1] == '2' ? 3 : 0)));   // k64 | k32 | k256
-    }();
-    return v;
-}
-
 }  // namespace
 
 extern "C" int hwgat_linear_nt_bf16(const void* A, const void* W, const float* bias, void* C, int64_t M, int N,
@@ -461,10 +450,7 @@ extern "C" int hwgat_linear_nt_bf16(const void* A, const void* W, const float* b
     NtArgsB a{(const bf16_t*)A, (const bf16_t*)W, bias, (bf16_t*)C, (bf16_t*)C2, (const bf16_t*)res,
               (const bf16_t*)aux, mean, rstd, gamma, beta, M, N, K, pro_seed, epi_seed, pro_p, epi_p};
     hipStream_t st = (hipStream_t)stream;
-    const bool k32 = bf16_tile_override() == 2;
-    // measured: the 8-wave 256x256 tile is slower here as well (26.4 vs 18.9 ms per step of NT time)
-    const bool big = bf16_tile_override() == 3 && M % 256 == 0 && N % 256 == 0;
-#define NTB_GO(P) return big ? launch_nt_b<P, NtB256>(a, epi, st) : (k32 ? launch_nt_b<P, NtB32>(a, epi, st) : launch_nt_b<P, NtB64>(a, epi, st))
+#define NTB_GO(P) return launch_nt_b<P, NtB64>(a, epi, st)
     switch (pro) {
         case PRO_NONE: NTB_GO(PRO_NONE);
         case PRO_LN: NTB_GO(PRO_LN);
