@@ -110,6 +110,7 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt
         for (int i = 0; i < PW; ++i)
             rw[i] = *reinterpret_cast<const u32x4*>(p.W + (int64_t)(it.n0 + lrow + RPP * i) * p.K + k0);
     };
+
     auto commit = [&](u32x4 (&ra)[PA], u32x4 (&rw)[PW], float (&lm)[PA], float (&lr)[PA], const SlabIt& it, int buf) {
         bf16_t* As = sm + buf * ((BM + BN) * LDT);
         bf16_t* Ws = As + BM * LDT;

@@ -61,6 +61,7 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt
 
     f32x4 ra[PA], rw[PW];
     float ln_mean[PA], ln_rstd[PA];
+    f32x4 ln_g, ln_b;                                          // gamma/beta of the staged slab, prefetched with it
 
     // XCD-aware tile order: blocks b, b+8, b+16, ... share an XCD (and its L2); give them the
     // n-tiles of ONE row block of A, so A streams from HBM once and is re-read from L2.
@@ -92,24 +93,20 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt
 #pragma unroll
         for (int i = 0; i < PW; ++i)
             rw[i] = *reinterpret_cast<const f32x4*>(p.W + (int64_t)(n0 + lrow + RPP * i) * p.K + k0);
+        if constexpr (PRO == PRO_LN) {
+            ln_g = *reinterpret_cast<const f32x4*>(p.gamma + k0);
+            ln_b = *reinterpret_cast<const f32x4*>(p.beta + k0);
+        }
     };
     auto commit = [&](int buf, int64_t m0, int slab) {
         float* As = sm + buf * ((BM + BN) * LDT);
         float* Ws = As + BM * LDT;
         const int k0 = slab * BK + lc4;
-        f32x4 g, b;
-        if constexpr (PRO == PRO_LN) {
-            g = *reinterpret_cast<const f32x4*>(p.gamma + k0);
-            b = *reinterpret_cast<const f32x4*>(p.beta + k0);
-        }
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             f32x4 a = ra[i];
             if constexpr (PRO == PRO_LN) {
-                a.x = (a.x - ln_mean[i]) * ln_rstd[i] * g.x + b.x;
-                a.y = (a.y - ln_mean[i]) * ln_rstd[i] * g.y + b.y;
-                a.z = (a.z - ln_mean[i]) * ln_rstd[i] * g.z + b.z;
-                a.w = (a.w - ln_mean[i]) * ln_rstd[i] * g.w + b.w;
+                a = (a - ln_mean[i]) * (ln_rstd[i] * ln_g) + ln_b;
             } else if constexpr (PRO == PRO_DROP) {
                 if (pro_th) a *= drop_keep4(p.pro_seed, (uint64_t)(m0 + lrow + RPP * i) * p.K + k0, pro_th, pro_sc);
             }
