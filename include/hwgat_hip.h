@@ -100,6 +100,27 @@ int hwgat_win_attn_bwd(const void* qkv, const void* dO, void* dqkv, const uint32
                        const float* thr, int B, int F, int nW, int nH, int hd, int shifted,
                        int dtype, void* stream);
 
+/* ---- (f) rank 3, sibling model HGATE: fused BLOCK attention (MSA.forward of
+ * hwgat/models/HGATE.py:84-108) with block_partition / block_reverse / torch.roll
+ * (HGATE.py:30-47,184-207) as index math.  A block is 2 frames x KJ joints (all joints
+ * of the skeleton: 29 in HGATEParams), no part windows and no train-mode threshold.
+ *   qkv      (B, F, KJ, 3, nH, hd) `dtype`, o (B, F, KJ, nH, hd) `dtype`
+ *   maskbits (2, 64, 2) uint32: query slot i = tp*32 + joint (tp = frame of the pair);
+ *            bit j of word [s][i][kt] = key joint j of frame kt visible to query i;
+ *            s=0 adjacency only (HGATE.py:100-102), s=1 adjacency AND the shift mask
+ *            of the LAST block of a shifted layer (HGATE.py:96-98,154-172).  Slots
+ *            with joint >= KJ are padding: never read, written or counted as keys.
+ *   shifted  1 for odd blocks (roll by -1 frame before, +1 after; HGATE.py:185-207)
+ * F even, 1 <= KJ <= 32, hd in {32, 64}. */
+int hwgat_blk_attn_fwd(const void* qkv, void* o, const uint32_t* maskbits,
+                       int B, int F, int KJ, int nH, int hd, int shifted, int dtype,
+                       void* stream);
+
+/* backward: do (B,F,KJ,nH,hd) -> dqkv (B,F,KJ,3,nH,hd); probabilities recomputed. */
+int hwgat_blk_attn_bwd(const void* qkv, const void* dO, void* dqkv, const uint32_t* maskbits,
+                       int B, int F, int KJ, int nH, int hd, int shifted, int dtype,
+                       void* stream);
+
 /* ---- a-11: final LayerNorm + mean over all f*K tokens (HWGATE.py:353-354).
  *   x (B, n_tok, d) `dtype`; feat (B, d) fp32 must be ZERO on entry (sums of
  *   normalised values are accumulated, then hwgat_lnpool_finish scales them);

@@ -11,6 +11,7 @@ from . import _lib
 from . import functional
 from .parts import part_table
 from .models.HWGATE import Model
-from .models.model_params import HWGATEParams
+from .models.HGATE import Model as HGATEModel
+from .models.model_params import HWGATEParams, HGATEParams
 
-__all__ = ["Model", "HWGATEParams", "functional", "part_table", "_lib"]
+__all__ = ["Model", "HWGATEParams", "HGATEModel", "HGATEParams", "functional", "part_table", "_lib"]

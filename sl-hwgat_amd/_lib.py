@@ -29,6 +29,8 @@ _SIGS = {
     "hwgat_ln_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
     "hwgat_win_attn_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "hwgat_win_attn_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "hwgat_blk_attn_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "hwgat_blk_attn_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "hwgat_lnpool_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "hwgat_lnpool_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "hwgat_merge": [_P, _P, _I, _I, _I, _I, _I, _I, _P],

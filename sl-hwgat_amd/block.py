@@ -1,4 +1,4 @@
-"""One PartAttentionBlock (reference hwgat/models/HWGATE.py:189-221) as a single autograd
+"""One PartAttentionBlock (reference hwgat/models/HWGATE.py:189-221; likewise HGATE.py:175-213) as a single autograd
 node whose forward and backward are sequences of HIP launches only.
 
 forward  (5 GEMM launches + 2 stats + 1 attention; the reference runs ~40 ATen ops):
@@ -66,15 +66,14 @@ class _DwQueue:
 class _FusedBlock(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, thr, n1w, n1b, wqkv, bqkv, wp, bp, n2w, n2b, w1, b1, w2, b2, cfg):
-        bits, n_heads, shifted, p, seeds = cfg
+        bits, n_heads, shifted, p, seeds, kind = cfg
         B, F, K, d = x.shape
         dt = x.dtype                              # fp32, or bf16 activations with fp32 master weights
         cw = (lambda w: w) if dt == torch.float32 else (lambda w: w.to(dt))
         m1, r1 = HF.ln_stats(x, n1w, n1b)
         qkv = HF.linear_nt(x, cw(wqkv), bqkv, pro=HF.PRO_LN, ln=(m1, r1, n1w, n1b))
         o = torch.empty_like(x)
-        HF.call("hwgat_win_attn_fwd", HF.ptr(qkv), HF.ptr(o), HF.ptr(bits), HF.ptr(thr), B, F, K // 16, n_heads,
-                d // n_heads, int(shifted), HF.dtype_code(x), HF.stream())
+        HF.attn_fwd(kind, qkv, o, bits, thr, n_heads, shifted)
         y = HF.linear_nt(o, cw(wp), bp, epi=HF.EPI_BIAS_DROP_RES, res=x, epi_seed=seeds[0], epi_p=p)
         m2, r2 = HF.ln_stats(y, n2w, n2b)
         u, h1 = HF.linear_nt(y, cw(w1), b1, pro=HF.PRO_LN, ln=(m2, r2, n2w, n2b), epi=HF.EPI_BIAS_GELU_DROP,
@@ -87,7 +86,7 @@ class _FusedBlock(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         x, thr, n1w, n1b, wqkv, wp, n2w, n2b, w1, w2, m1, r1, qkv, o, y, m2, r2, h1, u = ctx.saved_tensors
-        bits, n_heads, shifted, p, seeds = ctx.cfg
+        bits, n_heads, shifted, p, seeds, kind = ctx.cfg
         B, F, K, d = x.shape
         dt = x.dtype
         dout = dout.contiguous()
@@ -111,8 +110,7 @@ class _FusedBlock(torch.autograd.Function):
         d_o = HF.linear_nt(d_y, HF.transpose(wp, dt), None, pro=HF.PRO_DROP, pro_seed=seeds[0], pro_p=p,
                            epi=HF.EPI_NONE, out=d_z)
         dqkv = torch.empty_like(qkv)
-        HF.call("hwgat_win_attn_bwd", HF.ptr(qkv), HF.ptr(d_o), HF.ptr(dqkv), HF.ptr(bits), HF.ptr(thr), B, F,
-                K // 16, n_heads, d // n_heads, int(shifted), HF.dtype_code(x), HF.stream())
+        HF.attn_bwd(kind, qkv, d_o, dqkv, bits, thr, n_heads, shifted)
         dwq.run(lambda: HF.linear_tn(dqkv, x, dwqkv, dbqkv, ln=(m1, r1, n1w, n1b)))
         d_xn = HF.linear_nt(dqkv, HF.transpose(wqkv, dt), None, epi=HF.EPI_NONE, out=d_o)
         dx = HF.ln_backward(d_xn, x, m1, r1, n1w, d_y, dn1w, dn1b)
@@ -120,10 +118,11 @@ class _FusedBlock(torch.autograd.Function):
         return (dx, None, dn1w, dn1b, dwqkv, dbqkv, dwp, dbp, dn2w, dn2b, dw1, db1, dw2, db2, None)
 
 
-def fused_block(x, thr, blk, bits, n_heads, shifted, p, seeds):
-    """x (B,F,K,d) fp32 contiguous; `blk` holds norm1/attn.qkv/attn.proj/norm2/ff.fc1/ff.fc2."""
+def fused_block(x, thr, blk, bits, n_heads, shifted, p, seeds, kind="win"):
+    """x (B,F,K,d) fp32 contiguous; `blk` holds norm1/attn.qkv/attn.proj/norm2/ff.fc1/ff.fc2.
+    `kind`: 'win' = HWGATE part-window attention, 'blk' = HGATE block attention (thr must be None)."""
     return _FusedBlock.apply(
         x, thr, blk.norm1.weight, blk.norm1.bias, blk.attn.qkv.weight, blk.attn.qkv.bias,
         blk.attn.proj.weight, blk.attn.proj.bias, blk.norm2.weight, blk.norm2.bias,
         blk.ff.fc1.weight, blk.ff.fc1.bias, blk.ff.fc2.weight, blk.ff.fc2.bias,
-        (bits, n_heads, shifted, float(p), tuple(int(s) for s in seeds)))
+        (bits, n_heads, shifted, float(p), tuple(int(s) for s in seeds), kind))

@@ -58,6 +58,29 @@ def mask_bits(adj: torch.Tensor) -> torch.Tensor:
     return bits.contiguous()
 
 
+def blk_mask_bits(adj: torch.Tensor, n_joints: int) -> torch.Tensor:
+    """(2*KJ, 2*KJ) 0/1 block adjacency of HGATE (reference model_params.py:460-476) -> the (2,64,2)
+    uint32 rows `hwgat_blk_attn_*` consume.  Query slot i = tp*32 + joint; word [s][i][kt] has bit j
+    set iff key joint j of frame kt is visible: [0] adjacency only, [1] adjacency AND same frame (the
+    last block of a shifted layer, reference HGATE.py:154-172).  Pad slots (joint >= KJ) stay 0."""
+    KJ = int(n_joints)
+    a = adj.detach().to("cpu", torch.float32)
+    if not 1 <= KJ <= 32 or a.shape != (2 * KJ, 2 * KJ):
+        raise ValueError("block adjacency must be (2*K, 2*K) with K <= 32 (temporal_patch_size 2)")
+    if not bool(((a == 0) | (a == 1)).all()):
+        raise ValueError("adjacency must be a 0/1 matrix")
+    live = (a != 0).view(2, KJ, 2, KJ)                       # [tp_q][jq][tp_k][jk]
+    weights = (2 ** torch.arange(KJ, dtype=torch.int64))
+    plain = torch.zeros(2, 32, 2, dtype=torch.int64)
+    plain[:, :KJ] = (live.to(torch.int64) * weights).sum(-1)
+    last = plain.clone()
+    last[0, :, 1] = 0                                        # no cross-frame pairs
+    last[1, :, 0] = 0
+    bits = torch.stack([plain.view(64, 2), last.view(64, 2)])
+    bits = torch.where(bits >= 2 ** 31, bits - 2 ** 32, bits).to(torch.int32)
+    return bits.contiguous()
+
+
 # ---------------------------------------------------------------- embedding
 def embed(x, idx, bmat, pe, K, out_dtype=torch.float32, drop_p=0.0, seed=0):
     """gather + Fourier features + PE (+ dropout) (no gradient: B is frozen, PE a buffer)."""
@@ -123,6 +146,57 @@ class _WinAttn(torch.autograd.Function):
         call("hwgat_win_attn_bwd", ptr(qkv), ptr(do), ptr(dqkv), ptr(bits), ptr(thr), B, F, K // 16,
              n_heads, d // n_heads, shifted, dtype_code(qkv), stream())
         return dqkv, None, None, None, None
+
+
+def attn_fwd(kind, qkv, o, bits, thr, n_heads, shifted):
+    """launch the attention forward of a model family: 'win' = HWGATE part windows, 'blk' = HGATE blocks"""
+    B, F, K, d = o.shape
+    if kind == "win":
+        call("hwgat_win_attn_fwd", ptr(qkv), ptr(o), ptr(bits), ptr(thr), B, F, K // 16, n_heads, d // n_heads,
+             int(shifted), dtype_code(qkv), stream())
+    elif kind == "blk":
+        assert thr is None, "HGATE has no train-mode threshold"
+        call("hwgat_blk_attn_fwd", ptr(qkv), ptr(o), ptr(bits), B, F, K, n_heads, d // n_heads, int(shifted),
+             dtype_code(qkv), stream())
+    else:
+        raise ValueError(kind)
+
+
+def attn_bwd(kind, qkv, do, dqkv, bits, thr, n_heads, shifted):
+    B, F, K, d = do.shape
+    if kind == "win":
+        call("hwgat_win_attn_bwd", ptr(qkv), ptr(do), ptr(dqkv), ptr(bits), ptr(thr), B, F, K // 16, n_heads,
+             d // n_heads, int(shifted), dtype_code(qkv), stream())
+    elif kind == "blk":
+        call("hwgat_blk_attn_bwd", ptr(qkv), ptr(do), ptr(dqkv), ptr(bits), B, F, K, n_heads, d // n_heads,
+             int(shifted), dtype_code(qkv), stream())
+    else:
+        raise ValueError(kind)
+
+
+class _BlkAttn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, bits, n_heads, shifted):
+        B, F, K, d3 = qkv.shape
+        o = torch.empty(B, F, K, d3 // 3, device=qkv.device, dtype=qkv.dtype)
+        attn_fwd("blk", qkv, o, bits, None, n_heads, shifted)
+        ctx.save_for_backward(qkv, bits)
+        ctx.cfg = (n_heads, int(shifted))
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, bits = ctx.saved_tensors
+        n_heads, shifted = ctx.cfg
+        do = do.contiguous()
+        dqkv = torch.empty_like(qkv)
+        attn_bwd("blk", qkv, do, dqkv, bits, None, n_heads, shifted)
+        return dqkv, None, None, None
+
+
+def block_attention(qkv, bits, n_heads, shifted):
+    """HGATE: qkv (B,F,K,3d) -> o (B,F,K,d); a block = 2 frames x all K joints."""
+    return _BlkAttn.apply(qkv.contiguous(), bits, n_heads, shifted)
 
 
 def window_attention(qkv, bits, thr, n_heads, shifted):

@@ -52,6 +52,8 @@ def _last_slot_mask(frames, n_windows):
 
 
 class Model(nn.Module):
+    _attn_kind = "win"          # part-window attention (hwgat_win_attn_*); HGATE.Model overrides with "blk"
+
     def __init__(self, kp_dim=26, num_kps=64, temporal_dim=256, num_classes=1000, embed_dim=64,
                  temporal_patch_size=4, pe=False, depths=[2, 2, 6, 2], num_heads=[2, 4, 8, 16],
                  window_size=16, adj_mat=None, drop_rate=0., attn_drop_rate=0., ff_ratio=4.,
@@ -159,10 +161,14 @@ class Model(nn.Module):
     def _block(self, h, blk, n_heads, shifted, thr, k=0):
         if self.fused_linears and (h.numel() // h.shape[-1]) % 128 == 0:
             p = self.drop_rate if self.training else 0.0
-            return fused_block(h.contiguous(), thr, blk, self._mask_bits, n_heads, shifted, p, self._seeds(k))
+            return fused_block(h.contiguous(), thr, blk, self._mask_bits, n_heads, shifted, p, self._seeds(k),
+                               self._attn_kind)
         xn = HF.layer_norm(h, blk.norm1.weight, blk.norm1.bias)
         qkv = self._linear(xn, blk.attn.qkv)
-        o = HF.window_attention(qkv, self._mask_bits, thr, n_heads, shifted)
+        if self._attn_kind == "win":
+            o = HF.window_attention(qkv, self._mask_bits, thr, n_heads, shifted)
+        else:
+            o = HF.block_attention(qkv, self._mask_bits, n_heads, shifted)
         y = h + self._drop(self._linear(o, blk.attn.proj))
         z = HF.layer_norm(y, blk.norm2.weight, blk.norm2.bias)
         u = self._drop(tF.gelu(self._linear(z, blk.ff.fc1)))
@@ -186,7 +192,7 @@ class Model(nn.Module):
         for i, stage in enumerate(self.layers):
             for j, blk in enumerate(stage.blocks):
                 thr = None
-                if self.training:
+                if self.training and self._attn_kind == "win":     # HGATE has no threshold drop
                     if self.threshold_override is not None:
                         thr = torch.full((1,), float(self.threshold_override[k]), device=x.device)
                     else:

@@ -60,3 +60,54 @@ class HWGATEParams:
                 self.temporal_patch_size, self.pe, self.depths, self.num_heads, self.window_size,
                 self.adj_mat, self.drop_rate, self.attn_drop_rate, self.ff_ratio, self.norm_layer,
                 self.device)
+
+
+# 29-joint skeleton of the reference's HGATEParams (model_params.py:424-457): 9 upper-body joints and
+# two 10-joint hands with the same internal graph, rooted at joints 9 / 19 and hung from wrists 7 / 8.
+_BODY_EDGES = [(2, 0), (1, 0), (0, 3), (0, 4), (3, 5), (4, 6), (5, 7), (6, 8), (7, 9), (8, 19)]
+_HAND_EDGES = [(0, 1), (0, 2), (2, 3), (2, 4), (4, 5), (0, 4), (4, 6), (0, 6), (6, 7), (6, 8), (0, 8), (8, 9)]
+
+
+class HGATEParams:
+    """Drop-in for `HGATEParams` of the reference (model_params.py:405-486): same attributes, defaults and
+    positional tuple (no window_size: an attention block is all joints of 2 frames)."""
+
+    def __init__(self, dataset_params, input_dim, device=None, embed_dim=128):
+        self.kp_dim = input_dim
+        self.num_kps = 29
+        self.temporal_dim = dataset_params['src_len']
+        self.num_classes = dataset_params['num_class']
+        self.embed_dim = embed_dim
+        self.temporal_patch_size = 2
+        self.pe = True
+        self.depths = [2, 2, 4]
+        self.num_heads = [2, 4, 8]
+        self.drop_rate = 0.1
+        self.attn_drop_rate = 0.0
+        self.ff_ratio = 2.
+        self.norm_layer = nn.LayerNorm
+        self.device = device
+        self.edges = [[list(e) for e in _BODY_EDGES]
+                      + [[r + a, r + b] for r in (9, 19) for a, b in _HAND_EDGES]]
+        self.adj_mat = torch.tensor(self.get_adj_mat(), dtype=torch.float32)
+
+    def get_adj(self):
+        """I + symmetric joint graph (K x K)."""
+        a = np.eye(self.num_kps)
+        e = np.asarray(self.edges[0])
+        a[e[:, 0], e[:, 1]] = 1
+        a[e[:, 1], e[:, 0]] = 1
+        return a
+
+    def get_adj_mat(self):
+        """(TP*K, TP*K): same frame -> joint graph, neighbouring frame -> same joint only."""
+        TP, K = self.temporal_patch_size, self.num_kps
+        gap = np.abs(np.arange(TP)[:, None] - np.arange(TP)[None, :])
+        blocks = np.where(gap[:, :, None, None] == 0, self.get_adj(),
+                          np.where(gap[:, :, None, None] == 1, np.eye(K), 0.0))
+        return blocks.transpose(0, 2, 1, 3).reshape(TP * K, TP * K)
+
+    def get_model_params(self):
+        return (self.kp_dim, self.num_kps, self.temporal_dim, self.num_classes, self.embed_dim,
+                self.temporal_patch_size, self.pe, self.depths, self.num_heads, self.adj_mat,
+                self.drop_rate, self.attn_drop_rate, self.ff_ratio, self.norm_layer, self.device)

@@ -59,3 +59,14 @@ def grad_digest_check(named_grads, fx, prefix, tol):
         assert e2 < tol * 10, (name, "head", e2)
     assert n > 0
     return worst
+
+
+def hgate_oracle_from_fixture(fx, dtype=torch.float32):
+    """(OracleHGAT, params, cfg) of a tests/golden/hgate_*.npz fixture"""
+    from oracle import hgat_oracle as OH
+    T, K, C, d0, nc, B, seed = [int(v) for v in fx["cfg"]]
+    cfg = dict(kp_dim=C, temporal_dim=T, num_classes=nc, embed_dim=d0, depths=(2, 2, 4), ff_ratio=2.0,
+               use_pe=True, num_kps=K, tp=2)
+    params = {k: v.to(dtype) for k, v in O.synth_params(seed, weight_std=0.08, **cfg).items()}
+    model = OH.OracleHGAT(params, num_kps=K, temporal_dim=T, num_heads=[int(h) for h in fx["heads"]])
+    return model, params, cfg
