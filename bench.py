@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 
 CFG = dict(B=64, T=128, J=67, nW=5, C=2, d0=128, nc=2002)                     # BASELINE configs[1] (and [2] in bf16)
 CFG5 = dict(B=256, T=256, J=133, nW=7, C=3, d0=256, nc=2002)                  # BASELINE configs[4] "stress"
+CFG_HGATE = dict(B=64, T=128, J=29, K=29, C=2, d0=128, nc=2002)               # sibling model HGATE at the headline batch
 HBM_PEAK = 8.0e12           # B/s, MI355X_MICROARCH.md
 F32_MFMA_PEAK = 157.3e12    # FLOP/s
 
@@ -36,19 +37,24 @@ def attn_bytes(E, itemsize, bwd):
     return (7 if bwd else 4) * E * itemsize
 
 
-def cpu_baseline(sample_b=2, steps=2):
+def cpu_baseline(sample_b=2, steps=2, hgate=False):
     """oracle (CPU restatement proven equal to the reference) timed on the host cores:
     eval-mode fwd+bwd (the FASTEST reference variant) on a bounded
     sample of the same workload shape."""
     from oracle import hwgat_oracle as O
-    c = CFG
+    c = dict(CFG_HGATE, nW=None) if hgate else CFG
+    K = c["K"] if hgate else c["nW"] * 16
     torch.manual_seed(1001)
-    cfg = dict(kp_dim=c["C"], temporal_dim=c["T"], num_classes=c["nc"], embed_dim=c["d0"], num_kps=c["nW"] * 16)
+    cfg = dict(kp_dim=c["C"], temporal_dim=c["T"], num_classes=c["nc"], embed_dim=c["d0"], num_kps=K)
     params = {k: v.requires_grad_(k not in ("B", "pos_encoder.pe"))
               for k, v in O.synth_params(1, weight_std=0.02, **cfg).items()}
-    model = O.OracleHWGAT(params, num_kps=cfg["num_kps"], temporal_dim=c["T"])
+    if hgate:
+        from oracle import hgat_oracle as OH
+        model = OH.OracleHGAT(params, num_kps=K, temporal_dim=c["T"])
+    else:
+        model = O.OracleHWGAT(params, num_kps=K, temporal_dim=c["T"])
     g = torch.Generator().manual_seed(7)
-    x = torch.rand(sample_b, c["T"], c["nW"] * 16, c["C"], generator=g)
+    x = torch.rand(sample_b, c["T"], K, c["C"], generator=g)
     y = torch.randint(0, c["nc"], (sample_b,), generator=g)
     best, best_threads = None, None
     ncpu = os.cpu_count() or 1
@@ -66,7 +72,7 @@ def cpu_baseline(sample_b=2, steps=2):
     return {"value": round(sample_b / best, 3), "unit": "clips/s", "cores": best_threads,
             "kind": "port",
             "sample": f"oracle (torch CPU restatement) eval-mode fwd+bwd, B={sample_b} clips of the same "
-                      f"T={c['T']} K={c['nW'] * 16} C={c['C']} d0={c['d0']} shape, best of {steps} after 1 warm-up"}
+                      f"T={c['T']} K={K} C={c['C']} d0={c['d0']} shape, best of {steps} after 1 warm-up"}
 
 
 def main():
@@ -77,6 +83,9 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 5],
                     help="BASELINE config: 2 = fp32 headline (default), 3 = same in bf16, 5 = stress shape")
+    ap.add_argument("--model", default="hwgate", choices=["hwgate", "hgate"],
+                    help="hwgate = the headline model (default); hgate = sibling HGATE (29 joints, block attention) "
+                         "at the headline batch / frames / width")
     ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default: the config's)")
     ap.add_argument("--micro-batch", type=int, default=None, help="gradient-accumulation slice (clips)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -111,15 +120,20 @@ def main():
 
     if args.config == 3:
         args.dtype = "bf16"
-    base = CFG5 if args.config == 5 else CFG
+    hgate = args.model == "hgate"
+    base = CFG_HGATE if hgate else (CFG5 if args.config == 5 else CFG)
     c = dict(base, B=args.batch or base["B"])
+    K = c["K"] if hgate else c["nW"] * 16
     if args.config == 5 and args.micro_batch is None:
         args.micro_batch = 16 if args.dtype == "f32" else 32      # activation memory, DESIGN.md section 3
     torch.manual_seed(1001)                                       # reference configs.py:55-59
-    hp = hw.HWGATEParams({"src_len": c["T"], "num_class": c["nc"]}, c["C"], dev, num_kps=c["nW"] * 16,
-                         embed_dim=c["d0"])
-    model = hw.Model(*hp.get_model_params()).to(dev)
-    model.use_part_table(hw.part_table(c["J"], c["nW"]))
+    if hgate:
+        hp = hw.HGATEParams({"src_len": c["T"], "num_class": c["nc"]}, c["C"], dev, embed_dim=c["d0"])
+        model = hw.HGATEModel(*hp.get_model_params()).to(dev)
+    else:
+        hp = hw.HWGATEParams({"src_len": c["T"], "num_class": c["nc"]}, c["C"], dev, num_kps=K, embed_dim=c["d0"])
+        model = hw.Model(*hp.get_model_params()).to(dev)
+        model.use_part_table(hw.part_table(c["J"], c["nW"]))
     if args.dtype == "bf16":
         model.set_activation_dtype(torch.bfloat16)
     model.train(not args.eval_mode)
@@ -158,9 +172,10 @@ def main():
     if rank == 0:
         itemsize = 4 if args.dtype == "f32" else 2
         b_launch = min(args.micro_batch or c["B"], c["B"])            # clips per attention launch
-        E = b_launch * c["T"] * c["nW"] * 16 * c["d0"]
+        E = b_launch * c["T"] * K * c["d0"]
         kern = {}
-        for name, bwd in (("hwgat_win_attn_fwd", False), ("hwgat_win_attn_bwd", True)):
+        attn = "hwgat_blk_attn" if hgate else "hwgat_win_attn"
+        for name, bwd in ((attn + "_fwd", False), (attn + "_bwd", True)):
             n, ms = timers.get(name, (0, 0.0))
             if n:
                 avg = ms / n * 1e-3
@@ -196,17 +211,20 @@ def main():
         others = {k: {"launches": v[0], "total_ms": round(v[1], 3)} for k, v in timers.items()
                   if k not in kern}
         hip_ms = sum(v[1] for v in timers.values())
-        roof = dict(kern.get("hwgat_win_attn_bwd", {"bound": "hbm", "achieved": None, "peak": HBM_PEAK / 1e9,
+        roof = dict(kern.get(attn + "_bwd", {"bound": "hbm", "achieved": None, "peak": HBM_PEAK / 1e9,
                                                     "unit": "GB/s", "frac": None, "traffic": None}))
-        roof["kernel"] = "win_attn_bwd_k (fused window graph-attention backward)"
+        roof["kernel"] = ("blk_attn_bwd_k (fused block graph-attention backward, HGATE)" if hgate
+                          else "win_attn_bwd_k (fused window graph-attention backward)")
         out = {
             "metric": "clips/sec fwd+bwd at B=64 T=128 J=67; %HBM roofline; 1->8 GPU scaling",
             "value": round(world * c["B"] * args.steps / elapsed, 2), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[{ {2: 1, 3: 2, 5: 4}[args.config] }]: HWGAT train step (fwd+loss+bwd+AdamW), "
-                                   f"B={c['B']}/GPU T={c['T']} J={c['J']}->K={c['nW'] * 16} C={c['C']} "
+            "config": {"workload": ("sibling model HGATE at the headline shape" if hgate else
+                                    f"BASELINE configs[{ {2: 1, 3: 2, 5: 4}[args.config] }]")
+                                   + (": HGATE" if hgate else ": HWGAT") + " train step (fwd+loss+bwd+AdamW), "
+                                   f"B={c['B']}/GPU T={c['T']} J={c['J']}->K={K} C={c['C']} "
                                    f"d_model={c['d0']} depths[2,2,4] classes={c['nc']}, "
                                    + ("eval-mode" if args.eval_mode else "train-mode drop 0.1")
                                    + (f", micro-batch {args.micro_batch}" if args.micro_batch else ""),
@@ -217,7 +235,7 @@ def main():
             "loss": round(loss, 4),
         }
         if world == 1 and not args.no_cpu_baseline and args.config != 5:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(hgate=hgate)
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
