@@ -14,10 +14,10 @@
 //                                 key slots get probability exactly 0 and never count in max / sum
 //   O_qt = sum_kt P[kt] V_kt      P fed straight back as the MFMA A operand
 //
-// One 64-lane wavefront (= one workgroup) owns a unit end to end with private LDS: no workgroup
-// barriers.  The backward pass keeps Q, K, V, dO (2 tiles each) in LDS, runs the two query tiles as two
-// passes and accumulates dK / dV across them in registers; P^T and dS^T go through one LDS scratch tile
-// that is reused for both.
+// A workgroup of two wavefronts owns a unit: wave w loads frame tile w and owns query tile w (and, in
+// the second half of the backward pass, key tile w), so the per-wave register and LDS footprints are
+// half a unit's and 4 (bwd) / 8 (fwd) waves fit a CU.  The backward pass keeps Q, K, dO in LDS (V only
+// feeds dP and goes straight to registers); P^T and dS^T meet in one shared scratch tile.
 //
 // HBM traffic is the algorithmic 4*E*s (fwd) / 7*E*s (bwd) like the window kernel; the MFMA work per
 // byte is 2 x (64/58)^2 higher (64-slot tiles for 58 tokens), so at head_dim 64 the backward pass sits
@@ -96,17 +96,18 @@ template <typename T, int HD> struct BlkCfg {
 };
 
 // =============================================================== forward
+// Two wavefronts share a unit: wave w loads frame tile w of Q and K and owns query tile w.
 template <typename T, int HD>
-__global__ __launch_bounds__(64) void blk_attn_fwd_k(const T* __restrict__ qkv, T* __restrict__ o,
-                                                     const uint32_t* __restrict__ maskbits, BlkGeom g,
-                                                     int n_units) {
+__global__ __launch_bounds__(128, 2) void blk_attn_fwd_k(const T* __restrict__ qkv, T* __restrict__ o,
+                                                      const uint32_t* __restrict__ maskbits, BlkGeom g,
+                                                      int n_units) {
     using C = BlkCfg<T, HD>;
     constexpr int LDW = C::LDW, NT = C::NT, NLD = C::NLD, RPI = C::RPI, TILE = C::TILE;
     __shared__ __attribute__((aligned(16))) float smem[4 * TILE];      // Q0 Q1 K0 K1
     float* Qs = smem;
     float* Ks = smem + 2 * TILE;
 
-    const int lane = threadIdx.x, lq = lane & 31, hh = lane >> 5;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, lq = lane & 31, hh = lane >> 5;
     const int crow_l = lane / C::CPR, ccol = (lane % C::CPR) * C::EPV;
     const int64_t row3d = 3 * (int64_t)g.d;
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
@@ -114,20 +115,18 @@ __global__ __launch_bounds__(64) void blk_attn_fwd_k(const T* __restrict__ qkv, 
     int u = blockIdx.x;
     if (u >= n_units) return;
 
-    u32x4 qr[2][NLD], kr[2][NLD];
+    u32x4 qr[NLD], kr[NLD];
     auto issue_qk = [&](const BUnit& un) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int i = 0; i < NLD; ++i) {
-                const int j = i * RPI + crow_l;                 // pad rows re-read row KJ-1 and are zeroed
-                const bool ok = j < g.KJ;
-                const T* p = qkv + (un.base[t] + (ok ? j : g.KJ - 1)) * row3d + un.head * HD + ccol;
-                const u32x4 a = *reinterpret_cast<const u32x4*>(p);
-                const u32x4 b = *reinterpret_cast<const u32x4*>(p + g.d);
-                qr[t][i] = ok ? a : zero4;
-                kr[t][i] = ok ? b : zero4;
-            }
+        for (int i = 0; i < NLD; ++i) {
+            const int j = i * RPI + crow_l;                     // pad rows re-read row KJ-1 and are zeroed
+            const bool ok = j < g.KJ;
+            const T* p = qkv + ((w ? un.base[1] : un.base[0]) + (ok ? j : g.KJ - 1)) * row3d + un.head * HD + ccol;
+            const u32x4 a = *reinterpret_cast<const u32x4*>(p);
+            const u32x4 b = *reinterpret_cast<const u32x4*>(p + g.d);
+            qr[i] = ok ? a : zero4;
+            kr[i] = ok ? b : zero4;
+        }
     };
     BUnit cur = decode_bunit(g, u);
     issue_qk(cur);
@@ -135,13 +134,11 @@ __global__ __launch_bounds__(64) void blk_attn_fwd_k(const T* __restrict__ qkv, 
     for (; u < n_units; u += gridDim.x) {
         // -- stage Q (pre-scaled, HGATE.py:91) and K
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int i = 0; i < NLD; ++i) {
-                const int off = (t * 32 + i * RPI + crow_l) * LDW + ccol;
-                chunk<T>::to_lds(Qs + off, qr[t][i], qk_scale<HD>());
-                chunk<T>::to_lds(Ks + off, kr[t][i], 1.0f);
-            }
+        for (int i = 0; i < NLD; ++i) {
+            const int off = (w * 32 + i * RPI + crow_l) * LDW + ccol;
+            chunk<T>::to_lds(Qs + off, qr[i], qk_scale<HD>());
+            chunk<T>::to_lds(Ks + off, kr[i], 1.0f);
+        }
         // -- V straight into the MFMA B-operand layout (pad rows = 0)
         float v[2][16][NT];
         {
@@ -155,73 +152,69 @@ __global__ __launch_bounds__(64) void blk_attn_fwd_k(const T* __restrict__ qkv, 
                     if (crow(r, hh) < g.KJ) load_nt<T, NT>(vb + (cur.base[kt] + crow(r, hh)) * row3d, v[kt][r]);
                 }
         }
-        uint32_t mb[2][2];
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-            mb[qt][0] = maskbits[(cur.mrow + qt * 32 + lq) * 2];
-            mb[qt][1] = maskbits[(cur.mrow + qt * 32 + lq) * 2 + 1];
-        }
+        const uint32_t mb0 = maskbits[(cur.mrow + w * 32 + lq) * 2];
+        const uint32_t mb1 = maskbits[(cur.mrow + w * 32 + lq) * 2 + 1];
+        const int64_t obase = w ? cur.base[1] : cur.base[0];
+        const int ohead = cur.head;
         const int un = u + gridDim.x;
-        BUnit nxt = cur;
-        if (un < n_units) { nxt = decode_bunit(g, un); issue_qk(nxt); }
-        lds_fence();
+        if (un < n_units) { cur = decode_bunit(g, un); issue_qk(cur); }
+        __syncthreads();
 
+        float s[2][16], p[2][16];
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-            float s[2][16], p[2][16];
+        for (int kt = 0; kt < 2; ++kt) {
+            f32x16 st = tile_xyT<HD, LDW>(Ks + kt * TILE, Qs + w * TILE, lq, hh);
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt) {
-                f32x16 st = tile_xyT<HD, LDW>(Ks + kt * TILE, Qs + qt * TILE, lq, hh);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s[kt][r] = st[r];
-            }
-            masked_softmax64(s, p, mb[qt][0], mb[qt][1], hh, g.KJ);
-
-            f32x16 oacc[NT];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) oacc[nt][i] = 0.f;
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        oacc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(p[kt][r], v[kt][r][nt], oacc[nt], 0, 0, 0);
-
-            // lane (c=lq, hh), reg r -> O[q = crow(r,hh)][c*NT + nt]
-            T* ob = o + cur.head * HD + lq * NT;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float ov[NT];
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) ov[nt] = oacc[nt][r];
-                if (crow(r, hh) < g.KJ) store_nt<T, NT>(ob + (cur.base[qt] + crow(r, hh)) * (int64_t)g.d, ov);
-            }
+            for (int r = 0; r < 16; ++r) s[kt][r] = st[r];
         }
-        lds_fence();
-        cur = nxt;
+        masked_softmax64(s, p, mb0, mb1, hh, g.KJ);
+
+        f32x16 oacc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) oacc[nt][i] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    oacc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(p[kt][r], v[kt][r][nt], oacc[nt], 0, 0, 0);
+
+        // lane (c=lq, hh), reg r -> O[q = crow(r,hh)][c*NT + nt]
+        T* ob = o + ohead * HD + lq * NT;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float ov[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) ov[nt] = oacc[nt][r];
+            if (crow(r, hh) < g.KJ) store_nt<T, NT>(ob + (obase + crow(r, hh)) * (int64_t)g.d, ov);
+        }
+        __syncthreads();                                         // both waves are done with this unit's tiles
     }
 }
 
 // =============================================================== backward
+// Two wavefronts share a unit.  Phase A: wave w owns QUERY tile w (recompute P, dP, dS, dQ_w).  The
+// transposed dS and P tiles meet in a shared scratch tile.  Phase B: wave w owns KEY tile w
+// (dK_w = sum_qt dS^T Q_qt, dV_w = sum_qt P^T dO_qt).  Q, K, dO live in LDS; V is only ever the
+// row-per-lane operand of dP, so it goes from HBM straight into registers.
 template <typename T, int HD>
-__global__ __launch_bounds__(64) void blk_attn_bwd_k(const T* __restrict__ qkv, const T* __restrict__ dO,
-                                                     T* __restrict__ dqkv,
-                                                     const uint32_t* __restrict__ maskbits, BlkGeom g,
-                                                     int n_units) {
+__global__ __launch_bounds__(128) void blk_attn_bwd_k(const T* __restrict__ qkv, const T* __restrict__ dO,
+                                                      T* __restrict__ dqkv,
+                                                      const uint32_t* __restrict__ maskbits, BlkGeom g,
+                                                      int n_units) {
     using C = BlkCfg<T, HD>;
     constexpr int LDW = C::LDW, NT = C::NT, NLD = C::NLD, RPI = C::RPI, TILE = C::TILE;
-    constexpr int TW = 66;                                   // scratch row stride: [32 q][64 key slots]
-    __shared__ __attribute__((aligned(16))) float smem[8 * TILE + 32 * TW];   // Q0 Q1 K0 K1 V0 V1 G0 G1 | scratch
+    constexpr int TW = 66;                                   // scratch row stride: [64 q slots][64 key slots]
+    __shared__ __attribute__((aligned(16))) float smem[6 * TILE + 64 * TW];   // Q0 Q1 K0 K1 G0 G1 | scratch
     float* Qs = smem;
     float* Ks = smem + 2 * TILE;
-    float* Vs = smem + 4 * TILE;
-    float* Gs = smem + 6 * TILE;
-    float* Sc = smem + 8 * TILE;
+    float* Gs = smem + 4 * TILE;
+    float* Sc = smem + 6 * TILE;
 
-    const int lane = threadIdx.x, lq = lane & 31, hh = lane >> 5;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, lq = lane & 31, hh = lane >> 5;
     const int crow_l = lane / C::CPR, ccol = (lane % C::CPR) * C::EPV;
     const int64_t row3d = 3 * (int64_t)g.d;
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
@@ -229,175 +222,166 @@ __global__ __launch_bounds__(64) void blk_attn_bwd_k(const T* __restrict__ qkv, 
     int u = blockIdx.x;
     if (u >= n_units) return;
 
-    u32x4 qr[2][NLD], kr[2][NLD], vr[2][NLD], gr[2][NLD];
+    u32x4 qr[NLD], kr[NLD], gr[NLD];
     auto issue_qk = [&](const BUnit& un) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int i = 0; i < NLD; ++i) {
-                const int j = i * RPI + crow_l;                 // pad rows re-read row KJ-1 and are zeroed
-                const bool ok = j < g.KJ;
-                const T* p = qkv + (un.base[t] + (ok ? j : g.KJ - 1)) * row3d + un.head * HD + ccol;
-                const u32x4 a = *reinterpret_cast<const u32x4*>(p);
-                const u32x4 b = *reinterpret_cast<const u32x4*>(p + g.d);
-                qr[t][i] = ok ? a : zero4;
-                kr[t][i] = ok ? b : zero4;
-            }
-    };
-    auto issue_vg = [&](const BUnit& un) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int i = 0; i < NLD; ++i) {
-                const int j = i * RPI + crow_l;
-                const bool ok = j < g.KJ;
-                const int64_t tk = un.base[t] + (ok ? j : g.KJ - 1);
-                const u32x4 a = *reinterpret_cast<const u32x4*>(qkv + tk * row3d + 2 * g.d + un.head * HD + ccol);
-                const u32x4 b = *reinterpret_cast<const u32x4*>(dO + tk * (int64_t)g.d + un.head * HD + ccol);
-                vr[t][i] = ok ? a : zero4;
-                gr[t][i] = ok ? b : zero4;
-            }
+        for (int i = 0; i < NLD; ++i) {
+            const int j = i * RPI + crow_l;                     // pad rows re-read row KJ-1 and are zeroed
+            const bool ok = j < g.KJ;
+            const T* p = qkv + ((w ? un.base[1] : un.base[0]) + (ok ? j : g.KJ - 1)) * row3d + un.head * HD + ccol;
+            const u32x4 a = *reinterpret_cast<const u32x4*>(p);
+            const u32x4 b = *reinterpret_cast<const u32x4*>(p + g.d);
+            qr[i] = ok ? a : zero4;
+            kr[i] = ok ? b : zero4;
+        }
     };
     BUnit cur = decode_bunit(g, u);
     issue_qk(cur);
 
     for (; u < n_units; u += gridDim.x) {
-        // -- q, k of this unit -> LDS; v, dO requested now and landed behind the first S product
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int i = 0; i < NLD; ++i) {
-                const int off = (t * 32 + i * RPI + crow_l) * LDW + ccol;
-                chunk<T>::to_lds(Qs + off, qr[t][i], qk_scale<HD>());
-                chunk<T>::to_lds(Ks + off, kr[t][i], 1.0f);
-            }
-        issue_vg(cur);
-        uint32_t mb[2][2];
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-            mb[qt][0] = maskbits[(cur.mrow + qt * 32 + lq) * 2];
-            mb[qt][1] = maskbits[(cur.mrow + qt * 32 + lq) * 2 + 1];
+        for (int i = 0; i < NLD; ++i) {
+            const int off = (w * 32 + i * RPI + crow_l) * LDW + ccol;
+            chunk<T>::to_lds(Qs + off, qr[i], qk_scale<HD>());
+            chunk<T>::to_lds(Ks + off, kr[i], 1.0f);
         }
-        lds_fence();
-
-        f32x16 dk[2][NT], dv[2][NT];
+        // dO tile w (to LDS behind the S product) and V rows in the row-per-lane operand layout
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) { dk[kt][nt][i] = 0.f; dv[kt][nt][i] = 0.f; }
-
-        BUnit nxt = cur;
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-            // recompute P for query tile qt (lane = query, regs = key slots)
-            float s[2][16], p[2][16], ds[2][16];
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt) {
-                f32x16 st = tile_xyT<HD, LDW>(Ks + kt * TILE, Qs + qt * TILE, lq, hh);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s[kt][r] = st[r];
-            }
-            const uint32_t nz = masked_softmax64(s, p, mb[qt][0], mb[qt][1], hh, g.KJ);
-            if (qt == 0) {
-                // v, dO have landed: stage them
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int i = 0; i < NLD; ++i) {
-                        const int off = (t * 32 + i * RPI + crow_l) * LDW + ccol;
-                        chunk<T>::to_lds(Vs + off, vr[t][i], 1.0f);
-                        chunk<T>::to_lds(Gs + off, gr[t][i], 1.0f);
-                    }
-                lds_fence();
-            }
-            // dP^T[key][q] = V dO^T ; dS = P (dP - delta) where the logit was kept
-            {
-                float delta = 0.f;
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt) {
-                    f32x16 dp = tile_xyT<HD, LDW>(Vs + kt * TILE, Gs + qt * TILE, lq, hh);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) { ds[kt][r] = dp[r]; delta += p[kt][r] * dp[r]; }
-                }
-                delta += partner(delta);
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        ds[kt][r] = ((nz >> (kt * 16 + r)) & 1u) ? p[kt][r] * (ds[kt][r] - delta) : 0.f;
-            }
-            f32x16 acc[NT];
-            // dQ_qt = scale * sum_kt dS[kt] K_kt   (A = dS in registers: lane = q)
-            tile_ay<HD, LDW, true>(ds[0], Ks, lq, hh, acc);
-            tile_ay<HD, LDW, false>(ds[1], Ks + TILE, lq, hh, acc);
-            {
-                T* base = dqkv + cur.head * HD + lq * NT;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float ov[NT];
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) ov[nt] = acc[nt][r] * qk_scale<HD>();
-                    if (crow(r, hh) < g.KJ) store_nt<T, NT>(base + (cur.base[qt] + crow(r, hh)) * row3d, ov);
-                }
-            }
-            if (qt == 1) {                                       // next unit's q, k land behind the dK / dV products
-                const int un = u + gridDim.x;
-                if (un < n_units) { nxt = decode_bunit(g, un); issue_qk(nxt); }
-            }
-            // transpose through the scratch tile: write [q][key slot], read [.][key = lane]
-            auto put = [&](const float (&x)[2][16]) {
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) {
-                        float* pp = Sc + lq * TW + kt * 32 + 8 * gq + 4 * hh;
-                        f32x2 a0 = {x[kt][4 * gq], x[kt][4 * gq + 1]}, a1 = {x[kt][4 * gq + 2], x[kt][4 * gq + 3]};
-                        reinterpret_cast<f32x2*>(pp)[0] = a0;
-                        reinterpret_cast<f32x2*>(pp)[1] = a1;
-                    }
-            };
-            float a[16];
-            // dK_kt += dS[kt]^T (scale*Q_qt)   (Qs already holds scale*Q)
-            put(ds);
-            lds_fence();
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) a[r] = Sc[crow(r, hh) * TW + kt * 32 + lq];
-                tile_ay<HD, LDW, false>(a, Qs + qt * TILE, lq, hh, dk[kt]);
-            }
-            lds_fence();
-            // dV_kt += P[kt]^T dO_qt
-            put(p);
-            lds_fence();
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) a[r] = Sc[crow(r, hh) * TW + kt * 32 + lq];
-                tile_ay<HD, LDW, false>(a, Gs + qt * TILE, lq, hh, dv[kt]);
-            }
-            lds_fence();
+        for (int i = 0; i < NLD; ++i) {
+            const int j = i * RPI + crow_l;
+            const bool ok = j < g.KJ;
+            const u32x4 a = *reinterpret_cast<const u32x4*>(dO + ((w ? cur.base[1] : cur.base[0]) + (ok ? j : g.KJ - 1)) * (int64_t)g.d
+                                                            + cur.head * HD + ccol);
+            gr[i] = ok ? a : zero4;
         }
-        // lane (c=lq, hh), reg r -> row key = crow(r,hh) of tile kt
+        float vx[2][HD / 8][4];                                  // V[key = kt*32 + lq][8m + 4hh + 0..3]
         {
-            T* base = dqkv + cur.head * HD + lq * NT;
+            const bool ok = lq < g.KJ;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                const T* vp = qkv + (cur.base[kt] + (ok ? lq : g.KJ - 1)) * row3d + 2 * g.d + cur.head * HD + 4 * hh;
+#pragma unroll
+                for (int m = 0; m < HD / 8; ++m) {
+                    load_nt<T, 4>(vp + 8 * m, vx[kt][m]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) vx[kt][m][e] = ok ? vx[kt][m][e] : 0.f;
+                }
+            }
+        }
+        const uint32_t mb0 = maskbits[(cur.mrow + w * 32 + lq) * 2];
+        const uint32_t mb1 = maskbits[(cur.mrow + w * 32 + lq) * 2 + 1];
+        const int64_t base_w = w ? cur.base[1] : cur.base[0];
+        const int head = cur.head;
+        __syncthreads();                                         // (1) Q, K of both frames staged
+
+        // ---------------- phase A: query tile w
+        float s[2][16], p[2][16], ds[2][16];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            f32x16 st = tile_xyT<HD, LDW>(Ks + kt * TILE, Qs + w * TILE, lq, hh);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kt][r] = st[r];
+        }
+        const uint32_t nz = masked_softmax64(s, p, mb0, mb1, hh, g.KJ);
+#pragma unroll
+        for (int i = 0; i < NLD; ++i)
+            chunk<T>::to_lds(Gs + (w * 32 + i * RPI + crow_l) * LDW + ccol, gr[i], 1.0f);
+        lds_fence();                                             // own dO tile visible to this wave
+        // dP^T[key][q] = V dO_w^T ; dS = P (dP - delta) where the logit was kept
+        {
+            float delta = 0.f;
+            const float* yr = Gs + (w * 32 + lq) * LDW + 4 * hh;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                f32x16 dp;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) dp[i] = 0.f;
+#pragma unroll
+                for (int m = 0; m < HD / 8; ++m) {
+                    const f32x4 yf = *reinterpret_cast<const f32x4*>(yr + 8 * m);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vx[kt][m][0], yf.x, dp, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vx[kt][m][1], yf.y, dp, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vx[kt][m][2], yf.z, dp, 0, 0, 0);
+                    dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vx[kt][m][3], yf.w, dp, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { ds[kt][r] = dp[r]; delta += p[kt][r] * dp[r]; }
+            }
+            delta += partner(delta);
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float kv[NT], vv[NT];
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) { kv[nt] = dk[kt][nt][r]; vv[nt] = dv[kt][nt][r]; }
-                    if (crow(r, hh) < g.KJ) {
-                        T* row = base + (cur.base[kt] + crow(r, hh)) * row3d;
-                        store_nt<T, NT>(row + g.d, kv);
-                        store_nt<T, NT>(row + 2 * g.d, vv);
-                    }
-                }
+                for (int r = 0; r < 16; ++r)
+                    ds[kt][r] = ((nz >> (kt * 16 + r)) & 1u) ? p[kt][r] * (ds[kt][r] - delta) : 0.f;
         }
-        cur = nxt;
+        // next unit's q, k land behind the remaining products
+        {
+            const int un = u + gridDim.x;
+            if (un < n_units) { cur = decode_bunit(g, un); issue_qk(cur); }
+        }
+        f32x16 acc[NT];
+        // dQ_w = scale * sum_kt dS[kt] K_kt   (A = dS in registers: lane = q)
+        tile_ay<HD, LDW, true>(ds[0], Ks, lq, hh, acc);
+        tile_ay<HD, LDW, false>(ds[1], Ks + TILE, lq, hh, acc);
+        T* gbase = dqkv + head * HD + lq * NT;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float ov[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) ov[nt] = acc[nt][r] * qk_scale<HD>();
+            if (crow(r, hh) < g.KJ) store_nt<T, NT>(gbase + (base_w + crow(r, hh)) * row3d, ov);
+        }
+        // scratch [q slot][key slot]: this wave writes its 32 query rows
+        auto put = [&](const float (&x)[2][16]) {
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    float* pp = Sc + (w * 32 + lq) * TW + kt * 32 + 8 * gq + 4 * hh;
+                    f32x2 a0 = {x[kt][4 * gq], x[kt][4 * gq + 1]}, a1 = {x[kt][4 * gq + 2], x[kt][4 * gq + 3]};
+                    reinterpret_cast<f32x2*>(pp)[0] = a0;
+                    reinterpret_cast<f32x2*>(pp)[1] = a1;
+                }
+        };
+        put(ds);
+        __syncthreads();                                         // (2) dS of both query tiles + both dO tiles visible
+
+        // ---------------- phase B: key tile w
+        float a[16];
+        // dK_w = sum_qt dS[qt][kt = w]^T (scale*Q_qt)   (Qs already holds scale*Q)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a[r] = Sc[(qt * 32 + crow(r, hh)) * TW + w * 32 + lq];
+            if (qt == 0) tile_ay<HD, LDW, true>(a, Qs, lq, hh, acc);
+            else tile_ay<HD, LDW, false>(a, Qs + TILE, lq, hh, acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float ov[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) ov[nt] = acc[nt][r];
+            if (crow(r, hh) < g.KJ) store_nt<T, NT>(gbase + (base_w + crow(r, hh)) * row3d + g.d, ov);
+        }
+        __syncthreads();                                         // (3) dS scratch consumed
+        put(p);
+        __syncthreads();                                         // (4) P of both query tiles visible
+        // dV_w = sum_qt P[qt][kt = w]^T dO_qt
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a[r] = Sc[(qt * 32 + crow(r, hh)) * TW + w * 32 + lq];
+            if (qt == 0) tile_ay<HD, LDW, true>(a, Gs, lq, hh, acc);
+            else tile_ay<HD, LDW, false>(a, Gs + TILE, lq, hh, acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float ov[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) ov[nt] = acc[nt][r];
+            if (crow(r, hh) < g.KJ) store_nt<T, NT>(gbase + (base_w + crow(r, hh)) * row3d + 2 * g.d, ov);
+        }
+        __syncthreads();                                         // (5) tiles + scratch free for the next unit
     }
 }
 
@@ -411,15 +395,15 @@ template <typename T, int HD>
 int launch_bfwd(const void* qkv, void* o, const uint32_t* mb, BlkGeom g, int n_units, hipStream_t st) {
     constexpr int per_cu = LDS_PER_CU / (4 * BlkCfg<T, HD>::TILE * 4);
     const int blocks = min(n_units, 256 * (per_cu > 8 ? 8 : per_cu));
-    blk_attn_fwd_k<T, HD><<<blocks, 64, 0, st>>>((const T*)qkv, (T*)o, mb, g, n_units);
+    blk_attn_fwd_k<T, HD><<<blocks, 128, 0, st>>>((const T*)qkv, (T*)o, mb, g, n_units);
     HWGAT_LAUNCH_CHECK();
 }
 template <typename T, int HD>
 int launch_bbwd(const void* qkv, const void* dO, void* dqkv, const uint32_t* mb, BlkGeom g, int n_units,
                 hipStream_t st) {
-    constexpr int per_cu = LDS_PER_CU / ((8 * BlkCfg<T, HD>::TILE + 32 * 66) * 4);
+    constexpr int per_cu = LDS_PER_CU / ((6 * BlkCfg<T, HD>::TILE + 64 * 66) * 4);
     const int blocks = min(n_units, 256 * (per_cu > 4 ? 4 : per_cu));
-    blk_attn_bwd_k<T, HD><<<blocks, 64, 0, st>>>((const T*)qkv, (const T*)dO, (T*)dqkv, mb, g, n_units);
+    blk_attn_bwd_k<T, HD><<<blocks, 128, 0, st>>>((const T*)qkv, (const T*)dO, (T*)dqkv, mb, g, n_units);
     HWGAT_LAUNCH_CHECK();
 }
 
