@@ -69,16 +69,16 @@ class Model(_base.Model):
             stage.blocks = nn.ModuleList()
             for j in range(depths[i]):
                 blk = _base._Slot()
-                blk.norm1 = nn.LayerNorm(d)
-                blk.attn = _base._Slot()
-                blk.attn.qkv = nn.Linear(d, 3 * d)
-                blk.attn.proj = nn.Linear(d, d)
+                blk.norm1 = nn.LayerNorm(d)          # registration order of HGATE.py:150-174 (state_dict key order)
                 blk.norm2 = nn.LayerNorm(d)
                 blk.ff = _base._Slot()
                 blk.ff.fc1 = nn.Linear(d, int(d * ff_ratio))
                 blk.ff.fc2 = nn.Linear(int(d * ff_ratio), d)
                 blk.register_buffer("attn_mask", _last_block_mask(temporal_dim // 2 ** i, num_kps)
                                     if j % 2 == 1 else None)
+                blk.attn = _base._Slot()
+                blk.attn.qkv = nn.Linear(d, 3 * d)
+                blk.attn.proj = nn.Linear(d, d)
                 stage.blocks.append(blk)
             self.layers.append(stage)
         self.norm = nn.LayerNorm(self.num_features)

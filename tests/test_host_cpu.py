@@ -99,25 +99,27 @@ def test_c_abi_rejects_bad_arguments_without_launching():
 
 @pytest.mark.skipif(not __import__("os").path.exists("/root/reference/hwgat/models/HWGATE.py"),
                     reason="reference tree only exists in the development container")
-def test_checkpoint_interchange_with_the_reference_class():
+@pytest.mark.parametrize("family", ["HWGATE", "HGATE"])
+def test_checkpoint_interchange_with_the_reference_class(family):
     """state_dict of this backend loads STRICTLY into the reference Model and vice versa
-    (SURVEY 8b / 8f-4).  Development container only; nothing here runs on the GPU box."""
+    (SURVEY 8b / 8f-4), for the headline model and the sibling HGATE (8f-3).
+    Development container only; nothing here runs on the GPU box."""
     import sys, types
     for name in ("timm", "timm.models", "timm.models.layers"):
         sys.modules.setdefault(name, types.ModuleType(name))
     sys.modules["timm.models.layers"].trunc_normal_ = torch.nn.init.trunc_normal_   # init-only import, HWGATE.py:4
     sys.path.insert(0, "/root/reference/hwgat")
     try:
-        ref_mod = importlib.import_module("models.HWGATE")
+        ref_mod = importlib.import_module("models." + family)
         ref_par = importlib.import_module("models.model_params")
     finally:
         sys.path.remove("/root/reference/hwgat")
-    rp = ref_par.HWGATEParams({"src_len": 64, "num_class": 11}, 2, torch.device("cpu"))
+    rp = getattr(ref_par, family + "Params")({"src_len": 64, "num_class": 11}, 2, torch.device("cpu"))
     ref = ref_mod.Model(*rp.get_model_params())
-    hp = hw.HWGATEParams({"src_len": 64, "num_class": 11}, 2, torch.device("cpu"))
+    hp = getattr(hw, family + "Params")({"src_len": 64, "num_class": 11}, 2, torch.device("cpu"))
     assert [type(a) for a in hp.get_model_params()] == [type(a) for a in rp.get_model_params()]
     assert torch.equal(hp.adj_mat, rp.adj_mat)
-    mine = hw.Model(*hp.get_model_params())
+    mine = (hw.Model if family == "HWGATE" else hw.HGATEModel)(*hp.get_model_params())
     sd_ref, sd_mine = ref.state_dict(), mine.state_dict()
     assert list(sd_ref.keys()) == list(sd_mine.keys())                       # same keys, same order
     assert all(sd_ref[k].shape == sd_mine[k].shape and sd_ref[k].dtype == sd_mine[k].dtype for k in sd_ref)
