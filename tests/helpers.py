@@ -70,3 +70,13 @@ def hgate_oracle_from_fixture(fx, dtype=torch.float32):
     params = {k: v.to(dtype) for k, v in O.synth_params(seed, weight_std=0.08, **cfg).items()}
     model = OH.OracleHGAT(params, num_kps=K, temporal_dim=T, num_heads=[int(h) for h in fx["heads"]])
     return model, params, cfg
+
+
+def wgate_oracle_from_fixture(fx, dtype=torch.float32):
+    """(OracleWGAT, params, cfg) of a tests/golden/wgate_*.npz fixture"""
+    from oracle import wgat_oracle as OW
+    T, nW, C, d0, nc, B, heads, depths, seed = [int(v) for v in fx["cfg"]]
+    cfg = dict(kp_dim=C, temporal_dim=T, num_classes=nc, embed_dim=d0, depths=depths, ff_ratio=2.0, use_pe=True)
+    params = {k: v.to(dtype) for k, v in OW.synth_params(seed, **cfg).items()}
+    model = OW.OracleWGAT(params, num_kps=nW * 16, temporal_dim=T, depths=depths, num_heads=heads)
+    return model, params, dict(cfg, num_kps=nW * 16, num_heads=heads)
