@@ -121,6 +121,27 @@ int hwgat_blk_attn_bwd(const void* qkv, const void* dO, void* dqkv, const uint32
                        int B, int F, int KJ, int nH, int hd, int shifted, int dtype,
                        void* stream);
 
+/* ---- (f) rank 3, sibling model WGATE: fused BAND attention (MSA.forward of
+ * hwgat/models/WGATE.py:87-108) with window_partition / window_reverse (WGATE.py:32-65)
+ * as index math.  A WGATE window is one 16-joint part window over ALL F frames with an
+ * additive 0 / -10000 mask (WGATE.py:97-100,190) from a block-tridiagonal adjacency
+ * (model_params.py:209-228): only keys of frames f-1, f, f+1 can carry weight.
+ *   qkv      (B, F, K, 3, nH, hd) `dtype`, o (B, F, K, nH, hd) `dtype`, K = nW*16
+ *   maskrows (nW, 16) uint64: bit (16*t + j) of row [w][i] = key joint j of frame
+ *            f-1+t (t = 0,1,2) visible to query joint i of frame f, the same for every f
+ *            (frames outside the clip are dropped by the kernel); every row must have at
+ *            least one visible key in t = 1 (the reference's adjacency has a unit diagonal)
+ * hd in {16, 32}; any F >= 1. */
+int hwgat_band_attn_fwd(const void* qkv, void* o, const uint64_t* maskrows,
+                        int B, int F, int nW, int nH, int hd, int dtype, void* stream);
+
+/* backward: do (B,F,K,nH,hd) -> dqkv (B,F,K,3,nH,hd); probabilities recomputed. */
+int hwgat_band_attn_bwd(const void* qkv, const void* dO, void* dqkv, const uint64_t* maskrows,
+                        int B, int F, int nW, int nH, int hd, int dtype, void* stream);
+
+/* debug: one v_mfma_f32_16x16x4_f32 with a (16x4), b (4x16) row-major -> out (64 lanes x 4 regs) */
+int hwgat_debug_mfma16x16x4(const float* a, const float* b, float* out, void* stream);
+
 /* ---- a-11: final LayerNorm + mean over all f*K tokens (HWGATE.py:353-354).
  *   x (B, n_tok, d) `dtype`; feat (B, d) fp32 must be ZERO on entry (sums of
  *   normalised values are accumulated, then hwgat_lnpool_finish scales them);

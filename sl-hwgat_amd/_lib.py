@@ -31,6 +31,9 @@ _SIGS = {
     "hwgat_win_attn_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "hwgat_blk_attn_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "hwgat_blk_attn_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "hwgat_band_attn_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "hwgat_band_attn_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "hwgat_debug_mfma16x16x4": [_P, _P, _P, _P],
     "hwgat_lnpool_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "hwgat_lnpool_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "hwgat_merge": [_P, _P, _I, _I, _I, _I, _I, _I, _P],

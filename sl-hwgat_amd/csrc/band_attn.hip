@@ -1,0 +1,469 @@
+// Fused band graph-attention for the WGATE sibling model on gfx950 (MI355X).
+//
+// Replaces MSA.forward's attention core of the reference's hwgat/models/WGATE.py:87-108 together with
+// window_partition / window_reverse (WGATE.py:32-65).  A WGATE window is one 16-joint body-part window
+// over ALL T frames (T*16 tokens) with an ADDITIVE 0 / -10000 mask built from a block-tridiagonal
+// adjacency (model_params.py:209-228): a query in frame f can only see keys of frames f-1, f, f+1 of its
+// own part window; everything else gets exp(s - 10000 - max) == 0 exactly in fp32.  The reference
+// materialises the dense (T*16)^2 score matrix per (clip, window, head); here it never exists:
+//
+//   unit = (clip, part window, head [, frame segment]): ONE wavefront walks the frames in order.
+//   tile = 16 query joints x 16 key joints of one (query frame, key frame) pair = one
+//          v_mfma_f32_16x16x4_f32 accumulator (4 registers per lane); three key tiles per query frame.
+//   S^T  = K Q^T : both operands are "lane = row, 4 consecutive head-dim elements" = one 16-byte
+//          global load per lane straight from the natural-order qkv tensor -- no LDS anywhere.
+//   softmax over the <= 48 candidate keys in registers (12 per lane + 2 cross-lane steps);
+//   O    = P V   : P is fed back as the MFMA A operand, V comes in as 4 dwords per lane.
+//   K / V tiles live in a 3-frame sliding register window, so every q, k, v element is read from
+//   HBM once and every o element written once: traffic = the algorithmic 4*E*s (fwd), 7*E*s (bwd).
+//
+// Backward: the transposed tiles (lane = key) that dK / dV need are obtained by running the S and dP
+// products a second time with the operands swapped (same registers), and the per-query softmax
+// statistics are moved across lanes with ds_bpermute -- still no LDS tile, no barrier.
+// dK / dV of a key frame collect the contributions of query frames f-1, f, f+1 in a sliding
+// 3-frame accumulator window and are stored once.
+#include "common.h"
+
+namespace {
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+struct BandGeom {
+    int F, K, nW, nH, d, seg, n_seg;      // seg = query frames per unit, n_seg = segments per clip
+};
+
+// D(16x16) += A(16x4) B(4x16): lane l supplies A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15];
+// register r of lane l is D[i = 4*(l>>4) + r][j = l&15].
+__device__ __forceinline__ f32x4v mfma16(float a, float b, f32x4v c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+template <int HD> __device__ __forceinline__ constexpr float band_scale() {
+    return HD == 16 ? 0.25f : 0.17677669529663687f;            // float(head_dim ** -0.5), WGATE.py:79,92
+}
+
+template <typename T> __device__ __forceinline__ f32x4v ld4(const T* p) {
+    if constexpr (sizeof(T) == 4) {
+        return *reinterpret_cast<const f32x4v*>(p);
+    } else {
+        const bf16x4 t = *reinterpret_cast<const bf16x4*>(p);
+        f32x4v r = {(float)t.x, (float)t.y, (float)t.z, (float)t.w};
+        return r;
+    }
+}
+template <typename T> __device__ __forceinline__ float ld1(const T* p) { return (float)*p; }
+template <typename T> __device__ __forceinline__ void st1(T* p, float v) { *p = (T)v; }
+
+__device__ __forceinline__ float xg_max(float v) {              // over the 4 lanes l, l^16, l^32, l^48
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float xg_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+
+// row-operand tile: X[row = l&15][c = 16*ch + 4*g + s]  (A or B^T operand of a head-dim contraction)
+template <int NC> struct RowT { f32x4v c[NC]; };
+// column-operand tile: X[row = 4*g + r][c = 16*ct + (l&15)]  (B operand of a row contraction)
+template <int NC> struct ColT { float v[NC][4]; };
+
+template <typename T, int NC>
+__device__ __forceinline__ RowT<NC> load_row(const T* base, int64_t row_stride, int lr, int g, float mul) {
+    RowT<NC> t;
+    const T* p = base + lr * row_stride + 4 * g;
+#pragma unroll
+    for (int ch = 0; ch < NC; ++ch) t.c[ch] = ld4<T>(p + 16 * ch) * mul;
+    return t;
+}
+template <typename T, int NC>
+__device__ __forceinline__ ColT<NC> load_col(const T* base, int64_t row_stride, int lr, int g, float mul) {
+    ColT<NC> t;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int ct = 0; ct < NC; ++ct) t.v[ct][r] = ld1<T>(base + (4 * g + r) * row_stride + 16 * ct + lr) * mul;
+    return t;
+}
+template <int NC> __device__ __forceinline__ RowT<NC> zero_row() {
+    RowT<NC> t;
+#pragma unroll
+    for (int ch = 0; ch < NC; ++ch) t.c[ch] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    return t;
+}
+template <int NC> __device__ __forceinline__ ColT<NC> zero_col() {
+    ColT<NC> t;
+#pragma unroll
+    for (int ct = 0; ct < NC; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t.v[ct][r] = 0.f;
+    return t;
+}
+
+// D[i][j] = sum_c X[i][c] Y[j][c] for two row-operand tiles: lane (j = l&15, g), reg r -> D[4g + r][j]
+template <int NC>
+__device__ __forceinline__ f32x4v dot_rows(const RowT<NC>& x, const RowT<NC>& y) {
+    f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ch = 0; ch < NC; ++ch) {
+        acc = mfma16(x.c[ch].x, y.c[ch].x, acc);
+        acc = mfma16(x.c[ch].y, y.c[ch].y, acc);
+        acc = mfma16(x.c[ch].z, y.c[ch].z, acc);
+        acc = mfma16(x.c[ch].w, y.c[ch].w, acc);
+    }
+    return acc;
+}
+// acc[ct] (16 x 16 cols) += A(16x16) Y where a[r] = A[i = l&15][k = 4g + r] and Y is a column-operand tile
+template <int NC>
+__device__ __forceinline__ void mul_cols(const f32x4v& a, const ColT<NC>& y, f32x4v (&acc)[NC]) {
+#pragma unroll
+    for (int ct = 0; ct < NC; ++ct) {
+        acc[ct] = mfma16(a.x, y.v[ct][0], acc[ct]);
+        acc[ct] = mfma16(a.y, y.v[ct][1], acc[ct]);
+        acc[ct] = mfma16(a.z, y.v[ct][2], acc[ct]);
+        acc[ct] = mfma16(a.w, y.v[ct][3], acc[ct]);
+    }
+}
+
+struct BandUnit {
+    int64_t tok0;          // token index of (clip, frame 0, first joint of the window)
+    int head, w, f0, f1;   // query frames [f0, f1)
+};
+__device__ __forceinline__ BandUnit decode_band(const BandGeom& g, int u) {
+    BandUnit r;
+    const int sgi = u % g.n_seg;
+    int t = u / g.n_seg;
+    r.head = t % g.nH;
+    t /= g.nH;
+    r.w = t % g.nW;
+    const int b = t / g.nW;
+    r.tok0 = (int64_t)b * g.F * g.K + r.w * 16;
+    r.f0 = sgi * g.seg;
+    r.f1 = min(g.F, r.f0 + g.seg);
+    return r;
+}
+
+// probabilities of one query row from its three key tiles; masked / out-of-clip entries are exactly 0
+// (additive -10000 of WGATE.py:97-100 underflows to 0 in fp32; the diagonal is always visible)
+__device__ __forceinline__ void band_softmax(const f32x4v (&s)[3], uint32_t vis, f32x4v (&p)[3], float& m_out,
+                                             float& linv_out) {
+    float m = -3.0e38f;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if ((vis >> (4 * t + r)) & 1u) m = fmaxf(m, s[t][r]);
+    m = xg_max(m);
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float e = ((vis >> (4 * t + r)) & 1u) ? __expf(s[t][r] - m) : 0.f;
+            p[t][r] = e;
+            sum += e;
+        }
+    sum = xg_sum(sum);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) p[t] *= inv;
+    m_out = m;
+    linv_out = inv;
+}
+
+// 12 visibility bits (3 key tiles x 4 key joints 4g+r) of query joint `lr` from its 48-bit mask row
+__device__ __forceinline__ uint32_t vis_q(uint64_t mrow, int g, bool has_prev, bool has_next) {
+    uint32_t v = 0;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) v |= (uint32_t)((mrow >> (16 * t + 4 * g)) & 0xFull) << (4 * t);
+    if (!has_prev) v &= ~0x00Fu;
+    if (!has_next) v &= ~0xF00u;
+    return v;
+}
+
+// =============================================================== forward
+template <typename T, int HD, int PF>
+__global__ __launch_bounds__(256) void band_attn_fwd_k(const T* __restrict__ qkv, T* __restrict__ o,
+                                                       const uint64_t* __restrict__ maskrows, BandGeom g,
+                                                       int n_units) {
+    constexpr int NC = HD / 16;
+    const int lane = threadIdx.x & 63, lr = lane & 15, gq = lane >> 4;
+    const int u = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (u >= n_units) return;
+    const BandUnit un = decode_band(g, u);
+    const int64_t rs = 3 * (int64_t)g.d;                         // qkv row stride (elements)
+    const T* qb = qkv + un.tok0 * rs + un.head * HD;
+    T* ob = o + un.tok0 * (int64_t)g.d + un.head * HD;
+    const int64_t fs = (int64_t)g.K * rs;                        // frame stride in qkv
+    const uint64_t mrow = maskrows[un.w * 16 + lr];
+
+    // sliding window: K (row operand) and V (column operand) of frames f-1, f, f+1
+    RowT<NC> kw[3];
+    ColT<NC> vw[3];
+    kw[0] = zero_row<NC>(); vw[0] = zero_col<NC>();
+    if (un.f0 > 0) {
+        kw[0] = load_row<T, NC>(qb + (un.f0 - 1) * fs + g.d, rs, lr, gq, 1.0f);
+        vw[0] = load_col<T, NC>(qb + (un.f0 - 1) * fs + 2 * g.d, rs, lr, gq, 1.0f);
+    }
+    kw[1] = load_row<T, NC>(qb + un.f0 * fs + g.d, rs, lr, gq, 1.0f);
+    vw[1] = load_col<T, NC>(qb + un.f0 * fs + 2 * g.d, rs, lr, gq, 1.0f);
+
+    // prefetch ring: slot i holds Q of frame f+i and K, V of frame f+i+1
+    RowT<NC> rq[PF], rk[PF];
+    ColT<NC> rv[PF];
+    auto fill = [&](int i, int f) {                              // f = query frame of the slot
+        rq[i] = zero_row<NC>(); rk[i] = zero_row<NC>(); rv[i] = zero_col<NC>();
+        if (f < un.f1) rq[i] = load_row<T, NC>(qb + f * fs, rs, lr, gq, band_scale<HD>());
+        if (f < un.f1 && f + 1 < g.F) {
+            rk[i] = load_row<T, NC>(qb + (f + 1) * fs + g.d, rs, lr, gq, 1.0f);
+            rv[i] = load_col<T, NC>(qb + (f + 1) * fs + 2 * g.d, rs, lr, gq, 1.0f);
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < PF; ++i) fill(i, un.f0 + i);
+
+    for (int fb = un.f0; fb < un.f1; fb += PF) {
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int f = fb + i;
+            if (f < un.f1) {
+                const RowT<NC> q = rq[i];
+                kw[2] = rk[i];
+                vw[2] = rv[i];
+                fill(i, f + PF);
+                f32x4v s[3], p[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) s[t] = dot_rows<NC>(kw[t], q);     // s[t][r] = S[q = lr][key = 4g + r]
+                float m, linv;
+                band_softmax(s, vis_q(mrow, gq, f > 0, f + 1 < g.F), p, m, linv);
+                f32x4v oacc[NC];
+#pragma unroll
+                for (int ct = 0; ct < NC; ++ct) oacc[ct] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int t = 0; t < 3; ++t) mul_cols<NC>(p[t], vw[t], oacc);
+                // lane (c = lr, g), reg r -> O[q = 4g + r][16 ct + c]
+                T* of = ob + (int64_t)f * g.K * g.d;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int ct = 0; ct < NC; ++ct) st1<T>(of + (4 * gq + r) * (int64_t)g.d + 16 * ct + lr, oacc[ct][r]);
+                kw[0] = kw[1]; kw[1] = kw[2];
+                vw[0] = vw[1]; vw[1] = vw[2];
+            }
+        }
+    }
+}
+
+// =============================================================== backward
+template <typename T, int HD, int PF>
+__global__ __launch_bounds__(256) void band_attn_bwd_k(const T* __restrict__ qkv, const T* __restrict__ dO,
+                                                       T* __restrict__ dqkv,
+                                                       const uint64_t* __restrict__ maskrows, BandGeom g,
+                                                       int n_units) {
+    constexpr int NC = HD / 16;
+    const int lane = threadIdx.x & 63, lr = lane & 15, gq = lane >> 4;
+    const int u = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (u >= n_units) return;
+    const BandUnit un = decode_band(g, u);                       // backward units always span the whole clip
+    const int64_t rs = 3 * (int64_t)g.d;
+    const int64_t fs = (int64_t)g.K * rs, gs = (int64_t)g.K * g.d;
+    const T* qb = qkv + un.tok0 * rs + un.head * HD;
+    const T* gb = dO + un.tok0 * (int64_t)g.d + un.head * HD;
+    T* db = dqkv + un.tok0 * rs + un.head * HD;
+    const uint64_t mrow = maskrows[un.w * 16 + lr];              // row of query joint lr
+    uint64_t mrow2[4];                                           // rows of query joints 4g + r (transposed tiles)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mrow2[r] = maskrows[un.w * 16 + 4 * gq + r];
+
+    struct KeyFrame { RowT<NC> k, v; ColT<NC> kc; };
+    auto load_key = [&](int f) {
+        KeyFrame x;
+        x.k = load_row<T, NC>(qb + f * fs + g.d, rs, lr, gq, 1.0f);
+        x.v = load_row<T, NC>(qb + f * fs + 2 * g.d, rs, lr, gq, 1.0f);
+        x.kc = load_col<T, NC>(qb + f * fs + g.d, rs, lr, gq, 1.0f);
+        return x;
+    };
+    auto zero_key = [&]() {
+        KeyFrame x;
+        x.k = zero_row<NC>(); x.v = zero_row<NC>(); x.kc = zero_col<NC>();
+        return x;
+    };
+    KeyFrame kw[3];
+    kw[0] = zero_key();
+    kw[1] = load_key(0);
+    kw[2] = zero_key();
+    f32x4v dk[3][NC], dv[3][NC];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int ct = 0; ct < NC; ++ct) { dk[t][ct] = f32x4v{0.f, 0.f, 0.f, 0.f}; dv[t][ct] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
+
+    // prefetch ring: slot i = query frame f+i: Q, dO (row + column operands) and the key frame f+i+1
+    struct QFrame { RowT<NC> q, go; ColT<NC> qc, gc; };
+    QFrame rq[PF];
+    KeyFrame rk[PF];
+    auto fill = [&](int i, int f) {
+        rq[i].q = zero_row<NC>(); rq[i].go = zero_row<NC>(); rq[i].qc = zero_col<NC>(); rq[i].gc = zero_col<NC>();
+        rk[i] = zero_key();
+        if (f < g.F) {
+            rq[i].q = load_row<T, NC>(qb + f * fs, rs, lr, gq, band_scale<HD>());
+            rq[i].qc = load_col<T, NC>(qb + f * fs, rs, lr, gq, band_scale<HD>());
+            rq[i].go = load_row<T, NC>(gb + f * gs, g.d, lr, gq, 1.0f);
+            rq[i].gc = load_col<T, NC>(gb + f * gs, g.d, lr, gq, 1.0f);
+        }
+        if (f + 1 < g.F) rk[i] = load_key(f + 1);
+    };
+#pragma unroll
+    for (int i = 0; i < PF; ++i) fill(i, i);
+
+    auto store_key = [&](int f, const f32x4v (&k)[NC], const f32x4v (&v)[NC]) {
+        T* row = db + f * fs;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int ct = 0; ct < NC; ++ct) {
+                st1<T>(row + (4 * gq + r) * rs + g.d + 16 * ct + lr, k[ct][r]);
+                st1<T>(row + (4 * gq + r) * rs + 2 * g.d + 16 * ct + lr, v[ct][r]);
+            }
+    };
+
+    for (int fb = 0; fb < g.F; fb += PF) {
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int f = fb + i;
+            if (f < g.F) {
+                const QFrame q = rq[i];
+                kw[2] = rk[i];
+                fill(i, f + PF);
+                const bool hp = f > 0, hn = f + 1 < g.F;
+                // ---- orientation 1: lane = query joint lr, registers = key joints 4g + r
+                f32x4v s[3], p[3], ds[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) s[t] = dot_rows<NC>(kw[t].k, q.q);
+                float m, linv;
+                band_softmax(s, vis_q(mrow, gq, hp, hn), p, m, linv);
+                float delta = 0.f;
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    ds[t] = dot_rows<NC>(kw[t].v, q.go);                       // dP[q = lr][key = 4g + r]
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) delta += p[t][r] * ds[t][r];
+                }
+                delta = xg_sum(delta);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) ds[t] = p[t] * (ds[t] - delta);
+                // dQ[q = 4g + r][c] = scale * sum_key dS[q][key] K[key][c]
+                f32x4v acc[NC];
+#pragma unroll
+                for (int ct = 0; ct < NC; ++ct) acc[ct] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int t = 0; t < 3; ++t) mul_cols<NC>(ds[t], kw[t].kc, acc);
+                {
+                    T* row = db + f * fs;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int ct = 0; ct < NC; ++ct)
+                            st1<T>(row + (4 * gq + r) * rs + 16 * ct + lr, acc[ct][r] * band_scale<HD>());
+                }
+                // ---- orientation 2: lane = key joint lr, registers = query joints 4g + r
+                float m2[4], l2[4], d2[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {                                  // statistics of query joint 4g + r
+                    m2[r] = __shfl(m, 4 * gq + r, 64);
+                    l2[r] = __shfl(linv, 4 * gq + r, 64);
+                    d2[r] = __shfl(delta, 4 * gq + r, 64);
+                }
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const bool tile_ok = (t == 0) ? hp : (t == 2) ? hn : true;
+                    const f32x4v s2 = dot_rows<NC>(q.q, kw[t].k);              // S[q = 4g + r][key = lr]
+                    const f32x4v dp2 = dot_rows<NC>(q.go, kw[t].v);
+                    f32x4v p2, ds2;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool vis = tile_ok && ((mrow2[r] >> (16 * t + lr)) & 1ull);
+                        p2[r] = vis ? __expf(s2[r] - m2[r]) * l2[r] : 0.f;
+                        ds2[r] = p2[r] * (dp2[r] - d2[r]);
+                    }
+                    mul_cols<NC>(ds2, q.qc, dk[t]);                            // dK[key][c] += sum_q dS[q][key] (scale*Q)[q][c]
+                    mul_cols<NC>(p2, q.gc, dv[t]);                             // dV[key][c] += sum_q P[q][key] dO[q][c]
+                }
+                // key frame f-1 has now seen query frames f-2, f-1, f: done
+                if (hp) store_key(f - 1, dk[0], dv[0]);
+#pragma unroll
+                for (int ct = 0; ct < NC; ++ct) {
+                    dk[0][ct] = dk[1][ct]; dk[1][ct] = dk[2][ct]; dk[2][ct] = f32x4v{0.f, 0.f, 0.f, 0.f};
+                    dv[0][ct] = dv[1][ct]; dv[1][ct] = dv[2][ct]; dv[2][ct] = f32x4v{0.f, 0.f, 0.f, 0.f};
+                }
+                kw[0] = kw[1]; kw[1] = kw[2];
+            }
+        }
+    }
+    store_key(g.F - 1, dk[0], dv[0]);                            // after the rotation the last key frame sits in slot 0
+}
+
+__global__ void mfma16_probe_k(const float* a, const float* b, float* out) {
+    const int lane = threadIdx.x;
+    f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+    // A[i][k] supplied by lane (i = lane&15, k = lane>>4); B[k][j] by lane (j = lane&15, k = lane>>4)
+    acc = mfma16(a[(lane & 15) * 4 + (lane >> 4)], b[(lane >> 4) * 16 + (lane & 15)], acc);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[lane * 4 + i] = acc[i];
+}
+
+bool band_ok(int B, int F, int nW, int nH, int hd) {
+    return B > 0 && F > 0 && nW > 0 && nH > 0 && (hd == 16 || hd == 32);
+}
+
+}  // namespace
+
+extern "C" int hwgat_debug_mfma16x16x4(const float* a, const float* b, float* out, void* stream) {
+    if (!a || !b || !out) return HWGAT_EINVAL;
+    mfma16_probe_k<<<1, 64, 0, (hipStream_t)stream>>>(a, b, out);
+    HWGAT_LAUNCH_CHECK();
+}
+
+extern "C" int hwgat_band_attn_fwd(const void* qkv, void* o, const uint64_t* maskrows, int B, int F, int nW,
+                                   int nH, int hd, int dtype, void* stream) {
+    if (!qkv || !o || !maskrows) return HWGAT_EINVAL;
+    if (!band_ok(B, F, nW, nH, hd)) return HWGAT_ESHAPE;
+    // enough wavefronts to fill the chip: split the clip into frame segments (1 halo frame of K, V each)
+    const int64_t base_units = (int64_t)B * nW * nH;
+    int n_seg = 1;
+    while (base_units * n_seg < 256 * 16 && F / (n_seg * 2) >= 8) n_seg *= 2;
+    const int seg = (F + n_seg - 1) / n_seg;
+    n_seg = (F + seg - 1) / seg;
+    BandGeom g{F, nW * 16, nW, nH, nH * hd, seg, n_seg};
+    const int64_t units = base_units * n_seg;
+    if (units > 0x7fffffff) return HWGAT_ESHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int blocks = (int)((units + 3) / 4);
+#define FWD(T)                                                                                                  \
+    if (hd == 16) band_attn_fwd_k<T, 16, 8><<<blocks, 256, 0, st>>>((const T*)qkv, (T*)o, maskrows, g, (int)units); \
+    else band_attn_fwd_k<T, 32, 4><<<blocks, 256, 0, st>>>((const T*)qkv, (T*)o, maskrows, g, (int)units);
+    if (dtype == HWGAT_F32) { FWD(float) }
+    else if (dtype == HWGAT_BF16) { FWD(bf16_t) }
+    else return HWGAT_EDTYPE;
+#undef FWD
+    HWGAT_LAUNCH_CHECK();
+}
+
+extern "C" int hwgat_band_attn_bwd(const void* qkv, const void* dO, void* dqkv, const uint64_t* maskrows, int B,
+                                   int F, int nW, int nH, int hd, int dtype, void* stream) {
+    if (!qkv || !dO || !dqkv || !maskrows) return HWGAT_EINVAL;
+    if (!band_ok(B, F, nW, nH, hd)) return HWGAT_ESHAPE;
+    BandGeom g{F, nW * 16, nW, nH, nH * hd, F, 1};
+    const int64_t units = (int64_t)B * nW * nH;
+    if (units > 0x7fffffff) return HWGAT_ESHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int blocks = (int)((units + 3) / 4);
+#define BWD(T)                                                                                                         \
+    if (hd == 16) band_attn_bwd_k<T, 16, 2><<<blocks, 256, 0, st>>>((const T*)qkv, (const T*)dO, (T*)dqkv, maskrows, g, (int)units); \
+    else band_attn_bwd_k<T, 32, 1><<<blocks, 256, 0, st>>>((const T*)qkv, (const T*)dO, (T*)dqkv, maskrows, g, (int)units);
+    if (dtype == HWGAT_F32) { BWD(float) }
+    else if (dtype == HWGAT_BF16) { BWD(bf16_t) }
+    else return HWGAT_EDTYPE;
+#undef BWD
+    HWGAT_LAUNCH_CHECK();
+}

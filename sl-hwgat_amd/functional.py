@@ -81,6 +81,39 @@ def blk_mask_bits(adj: torch.Tensor, n_joints: int) -> torch.Tensor:
     return bits.contiguous()
 
 
+def band_mask_rows(adj: torch.Tensor, frames: int) -> torch.Tensor:
+    """(nW, T*16, T*16) 0/1 adjacency of WGATE (reference model_params.py:209-228) -> the (nW,16) int64
+    rows `hwgat_band_attn_*` consume: bit 16*t + j of row [w][i] = key joint j of frame f-1+t visible to
+    query joint i of frame f.  The kernel never forms the (T*16)^2 matrix, so the adjacency must have the
+    structure the reference builds: block-tridiagonal over frames with the same three 16x16 blocks on
+    every frame, and a visible key in every row of the diagonal block.  Anything else raises."""
+    a = adj.detach().to("cpu")
+    T = int(frames)
+    if a.dim() != 3 or a.shape[1] != T * 16 or a.shape[2] != T * 16:
+        raise ValueError("WGATE adjacency must be (nW, T*16, T*16)")
+    nW = a.shape[0]
+    if not bool(((a == 0) | (a == 1)).all()):
+        raise ValueError("adjacency must be a 0/1 matrix")
+    blk = (a != 0).view(nW, T, 16, T, 16).permute(0, 1, 3, 2, 4)          # [w][fq][fk][i][j]
+    fq = torch.arange(T).view(T, 1)
+    fk = torch.arange(T).view(1, T)
+    off = (fk - fq)
+    if bool(blk[:, off.abs() > 1].any()):
+        raise NotImplementedError("WGATE HIP backend needs a block-tridiagonal adjacency (frames f-1, f, f+1)")
+    rows = torch.zeros(nW, 16, dtype=torch.int64)
+    weights = 2 ** torch.arange(16, dtype=torch.int64)
+    for t, o in enumerate((-1, 0, 1)):
+        sel = blk[:, off == o]                                            # (nW, n, 16, 16)
+        if sel.shape[1] == 0:
+            continue
+        if not bool((sel == sel[:, :1]).all()):
+            raise NotImplementedError("WGATE HIP backend needs the same adjacency blocks on every frame")
+        rows += (sel[:, 0].to(torch.int64) * weights).sum(-1) << (16 * t)
+    if not bool(((rows >> 16) & 0xFFFF).ne(0).all()):
+        raise NotImplementedError("every query joint needs a visible key in its own frame")
+    return rows.contiguous()
+
+
 # ---------------------------------------------------------------- embedding
 def embed(x, idx, bmat, pe, K, out_dtype=torch.float32, drop_p=0.0, seed=0):
     """gather + Fourier features + PE (+ dropout) (no gradient: B is frozen, PE a buffer)."""
@@ -158,6 +191,10 @@ def attn_fwd(kind, qkv, o, bits, thr, n_heads, shifted):
         assert thr is None, "HGATE has no train-mode threshold"
         call("hwgat_blk_attn_fwd", ptr(qkv), ptr(o), ptr(bits), B, F, K, n_heads, d // n_heads, int(shifted),
              dtype_code(qkv), stream())
+    elif kind == "band":
+        assert thr is None and not shifted, "WGATE has neither threshold nor shift"
+        call("hwgat_band_attn_fwd", ptr(qkv), ptr(o), ptr(bits), B, F, K // 16, n_heads, d // n_heads,
+             dtype_code(qkv), stream())
     else:
         raise ValueError(kind)
 
@@ -170,6 +207,9 @@ def attn_bwd(kind, qkv, do, dqkv, bits, thr, n_heads, shifted):
     elif kind == "blk":
         call("hwgat_blk_attn_bwd", ptr(qkv), ptr(do), ptr(dqkv), ptr(bits), B, F, K, n_heads, d // n_heads,
              int(shifted), dtype_code(qkv), stream())
+    elif kind == "band":
+        call("hwgat_band_attn_bwd", ptr(qkv), ptr(do), ptr(dqkv), ptr(bits), B, F, K // 16, n_heads, d // n_heads,
+             dtype_code(qkv), stream())
     else:
         raise ValueError(kind)
 
@@ -192,6 +232,30 @@ class _BlkAttn(torch.autograd.Function):
         dqkv = torch.empty_like(qkv)
         attn_bwd("blk", qkv, do, dqkv, bits, None, n_heads, shifted)
         return dqkv, None, None, None
+
+
+class _BandAttn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, rows, n_heads):
+        B, F, K, d3 = qkv.shape
+        o = torch.empty(B, F, K, d3 // 3, device=qkv.device, dtype=qkv.dtype)
+        attn_fwd("band", qkv, o, rows, None, n_heads, False)
+        ctx.save_for_backward(qkv, rows)
+        ctx.n_heads = n_heads
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, rows = ctx.saved_tensors
+        do = do.contiguous()
+        dqkv = torch.empty_like(qkv)
+        attn_bwd("band", qkv, do, dqkv, rows, None, ctx.n_heads, False)
+        return dqkv, None, None
+
+
+def band_attention(qkv, rows, n_heads):
+    """WGATE: qkv (B,F,K,3d) -> o (B,F,K,d); a window = one 16-joint part window over all F frames."""
+    return _BandAttn.apply(qkv.contiguous(), rows, n_heads)
 
 
 def block_attention(qkv, bits, n_heads, shifted):
