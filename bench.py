@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 CFG = dict(B=64, T=128, J=67, nW=5, C=2, d0=128, nc=2002)                     # BASELINE configs[1] (and [2] in bf16)
 CFG5 = dict(B=256, T=256, J=133, nW=7, C=3, d0=256, nc=2002)                  # BASELINE configs[4] "stress"
 CFG_HGATE = dict(B=64, T=128, J=29, K=29, C=2, d0=128, nc=2002)               # sibling model HGATE at the headline batch
+CFG_WGATE = dict(B=64, T=128, J=64, K=64, C=2, d0=128, nc=2002)               # sibling model WGATE (reference default K=64)
 HBM_PEAK = 8.0e12           # B/s, MI355X_MICROARCH.md
 F32_MFMA_PEAK = 157.3e12    # FLOP/s
 
@@ -35,6 +36,29 @@ def attn_bytes(E, itemsize, bwd):
     fwd reads q,k,v + writes o = 4E; bwd reads q,k,v,dO + writes dq,dk,dv = 7E
     (delta is recomputed in-kernel, so o is not re-read: 7E, not 8E)."""
     return (7 if bwd else 4) * E * itemsize
+
+
+def cpu_baseline_wgate(sample_b=1, steps=2):
+    """WGATE oracle (dense (T*16)^2 attention like the reference) on the host cores, eval-mode fwd+bwd"""
+    from oracle import wgat_oracle as OW
+    c = CFG_WGATE
+    cfg = dict(kp_dim=c["C"], temporal_dim=c["T"], num_classes=c["nc"], embed_dim=c["d0"])
+    params = {k: v.requires_grad_(k not in ("B", "pos_encoder.pe")) for k, v in OW.synth_params(1, weight_std=0.02, **cfg).items()}
+    model = OW.OracleWGAT(params, num_kps=c["K"], temporal_dim=c["T"])
+    g = torch.Generator().manual_seed(7)
+    x = torch.rand(sample_b, c["T"], c["K"], c["C"], generator=g)
+    y = torch.randint(0, c["nc"], (sample_b,), generator=g)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    times = []
+    for i in range(steps + 1):
+        for p in params.values():
+            p.grad = None
+        t0 = time.perf_counter()
+        OW.smoothed_cross_entropy(model.forward(x), y).backward()
+        times.append(time.perf_counter() - t0)
+    return {"value": round(sample_b / min(times[1:]), 3), "unit": "clips/s", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": f"WGATE oracle eval-mode fwd+bwd, B={sample_b} clip of the same T={c['T']} "
+                                      f"K={c['K']} d0={c['d0']} shape, best of {steps} after 1 warm-up"}
 
 
 def cpu_baseline(sample_b=2, steps=2, hgate=False):
@@ -83,8 +107,8 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 5],
                     help="BASELINE config: 2 = fp32 headline (default), 3 = same in bf16, 5 = stress shape")
-    ap.add_argument("--model", default="hwgate", choices=["hwgate", "hgate"],
-                    help="hwgate = the headline model (default); hgate = sibling HGATE (29 joints, block attention) "
+    ap.add_argument("--model", default="hwgate", choices=["hwgate", "hgate", "wgate"],
+                    help="hwgate = the headline model (default); hgate / wgate = the sibling models (SURVEY 8f rank 3) "
                          "at the headline batch / frames / width")
     ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default: the config's)")
     ap.add_argument("--micro-batch", type=int, default=None, help="gradient-accumulation slice (clips)")
@@ -120,16 +144,19 @@ def main():
 
     if args.config == 3:
         args.dtype = "bf16"
-    hgate = args.model == "hgate"
-    base = CFG_HGATE if hgate else (CFG5 if args.config == 5 else CFG)
+    hgate, wgate = args.model == "hgate", args.model == "wgate"
+    base = CFG_HGATE if hgate else CFG_WGATE if wgate else (CFG5 if args.config == 5 else CFG)
     c = dict(base, B=args.batch or base["B"])
-    K = c["K"] if hgate else c["nW"] * 16
+    K = c["K"] if (hgate or wgate) else c["nW"] * 16
     if args.config == 5 and args.micro_batch is None:
         args.micro_batch = 16 if args.dtype == "f32" else 32      # activation memory, DESIGN.md section 3
     torch.manual_seed(1001)                                       # reference configs.py:55-59
     if hgate:
         hp = hw.HGATEParams({"src_len": c["T"], "num_class": c["nc"]}, c["C"], dev, embed_dim=c["d0"])
         model = hw.HGATEModel(*hp.get_model_params()).to(dev)
+    elif wgate:
+        hp = hw.WGATEParams({"src_len": c["T"], "num_class": c["nc"]}, c["C"], dev, num_kps=K, embed_dim=c["d0"])
+        model = hw.WGATEModel(*hp.get_model_params()).to(dev)
     else:
         hp = hw.HWGATEParams({"src_len": c["T"], "num_class": c["nc"]}, c["C"], dev, num_kps=K, embed_dim=c["d0"])
         model = hw.Model(*hp.get_model_params()).to(dev)
@@ -174,7 +201,7 @@ def main():
         b_launch = min(args.micro_batch or c["B"], c["B"])            # clips per attention launch
         E = b_launch * c["T"] * K * c["d0"]
         kern = {}
-        attn = "hwgat_blk_attn" if hgate else "hwgat_win_attn"
+        attn = "hwgat_blk_attn" if hgate else "hwgat_band_attn" if wgate else "hwgat_win_attn"
         for name, bwd in ((attn + "_fwd", False), (attn + "_bwd", True)):
             n, ms = timers.get(name, (0, 0.0))
             if n:
@@ -195,7 +222,7 @@ def main():
         except (OSError, KeyError):
             pass
         # linears: useful flops per step (fwd + dX + dW = 3 x 16*E*d_i per block) against the dense MFMA peak
-        sum_d = sum(dep * c["d0"] * 2 ** i for i, dep in enumerate((2, 2, 4)))
+        sum_d = 8 * c["d0"] if wgate else sum(dep * c["d0"] * 2 ** i for i, dep in enumerate((2, 2, 4)))
         n_micro = -(-c["B"] // b_launch)
         flops_fwd = 16.0 * E * sum_d * n_micro                        # per step, forward linears
         peak = F32_MFMA_PEAK if args.dtype == "f32" else 2.5e15
@@ -214,6 +241,7 @@ def main():
         roof = dict(kern.get(attn + "_bwd", {"bound": "hbm", "achieved": None, "peak": HBM_PEAK / 1e9,
                                                     "unit": "GB/s", "frac": None, "traffic": None}))
         roof["kernel"] = ("blk_attn_bwd_k (fused block graph-attention backward, HGATE)" if hgate
+                          else "band_attn_bwd_k (fused band graph-attention backward, WGATE)" if wgate
                           else "win_attn_bwd_k (fused window graph-attention backward)")
         out = {
             "metric": "clips/sec fwd+bwd at B=64 T=128 J=67; %HBM roofline; 1->8 GPU scaling",
@@ -222,10 +250,11 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": ("sibling model HGATE at the headline shape" if hgate else
+                                    "sibling model WGATE at the headline shape" if wgate else
                                     f"BASELINE configs[{ {2: 1, 3: 2, 5: 4}[args.config] }]")
-                                   + (": HGATE" if hgate else ": HWGAT") + " train step (fwd+loss+bwd+AdamW), "
+                                   + (": HGATE" if hgate else ": WGATE" if wgate else ": HWGAT") + " train step (fwd+loss+bwd+AdamW), "
                                    f"B={c['B']}/GPU T={c['T']} J={c['J']}->K={K} C={c['C']} "
-                                   f"d_model={c['d0']} depths[2,2,4] classes={c['nc']}, "
+                                   f"d_model={c['d0']} " + ("8 blocks" if wgate else "depths[2,2,4]") + f" classes={c['nc']}, "
                                    + ("eval-mode" if args.eval_mode else "train-mode drop 0.1")
                                    + (f", micro-batch {args.micro_batch}" if args.micro_batch else ""),
                        "global_batch": world * c["B"], "parallelism": f"dp{world}"},
@@ -235,7 +264,7 @@ def main():
             "loss": round(loss, 4),
         }
         if world == 1 and not args.no_cpu_baseline and args.config != 5:
-            out["cpu_baseline"] = cpu_baseline(hgate=hgate)
+            out["cpu_baseline"] = cpu_baseline_wgate() if wgate else cpu_baseline(hgate=hgate)
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()

@@ -12,6 +12,8 @@ from . import functional
 from .parts import part_table
 from .models.HWGATE import Model
 from .models.HGATE import Model as HGATEModel
-from .models.model_params import HWGATEParams, HGATEParams
+from .models.WGATE import Model as WGATEModel
+from .models.model_params import HWGATEParams, HGATEParams, WGATEParams
 
-__all__ = ["Model", "HWGATEParams", "HGATEModel", "HGATEParams", "functional", "part_table", "_lib"]
+__all__ = ["Model", "HWGATEParams", "HGATEModel", "HGATEParams", "WGATEModel", "WGATEParams", "functional",
+           "part_table", "_lib"]

@@ -52,7 +52,7 @@ def _last_slot_mask(frames, n_windows):
 
 
 class Model(nn.Module):
-    _attn_kind = "win"          # part-window attention (hwgat_win_attn_*); HGATE.Model overrides with "blk"
+    _attn_kind = "win"          # part-window attention (hwgat_win_attn_*); HGATE overrides with "blk", WGATE with "band"
 
     def __init__(self, kp_dim=26, num_kps=64, temporal_dim=256, num_classes=1000, embed_dim=64,
                  temporal_patch_size=4, pe=False, depths=[2, 2, 6, 2], num_heads=[2, 4, 8, 16],
@@ -167,8 +167,10 @@ class Model(nn.Module):
         qkv = self._linear(xn, blk.attn.qkv)
         if self._attn_kind == "win":
             o = HF.window_attention(qkv, self._mask_bits, thr, n_heads, shifted)
-        else:
+        elif self._attn_kind == "blk":
             o = HF.block_attention(qkv, self._mask_bits, n_heads, shifted)
+        else:
+            o = HF.band_attention(qkv, self._mask_bits, n_heads)
         y = h + self._drop(self._linear(o, blk.attn.proj))
         z = HF.layer_norm(y, blk.norm2.weight, blk.norm2.bias)
         u = self._drop(tF.gelu(self._linear(z, blk.ff.fc1)))

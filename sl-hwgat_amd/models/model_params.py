@@ -111,3 +111,50 @@ class HGATEParams:
         return (self.kp_dim, self.num_kps, self.temporal_dim, self.num_classes, self.embed_dim,
                 self.temporal_patch_size, self.pe, self.depths, self.num_heads, self.adj_mat,
                 self.drop_rate, self.attn_drop_rate, self.ff_ratio, self.norm_layer, self.device)
+
+
+class WGATEParams:
+    """Drop-in for `WGATEParams` of the reference (model_params.py:80-241): same attributes, defaults and
+    positional tuple.  The adjacency is the dense (nW, T*16, T*16) block-tridiagonal matrix the
+    reference builds (same frame -> part graph, neighbouring frame -> same joint)."""
+
+    def __init__(self, dataset_params, input_dim, device=None, num_kps=64, embed_dim=128):
+        self.kp_dim = input_dim
+        self.num_kps = num_kps
+        self.temporal_dim = dataset_params['src_len']
+        self.num_classes = dataset_params['num_class']
+        self.embed_dim = embed_dim
+        self.pe = True
+        self.depths = 8
+        self.num_heads = 8
+        self.window_size = 16
+        self.drop_rate = 0.1
+        self.attn_drop_rate = 0.0
+        self.ff_ratio = 2.
+        self.norm_layer = nn.LayerNorm
+        self.kp_norm = True
+        self.device = device
+        self.edges = [[list(e) for e in _PART_EDGES] for _ in range(self.num_kps // self.window_size)]
+        self.adj_mat = torch.tensor(self.get_adj_mat(), dtype=torch.float32)
+
+    def get_adj(self, index):
+        a = np.eye(self.window_size)
+        e = np.asarray(self.edges[index])
+        a[e[:, 0], e[:, 1]] = 1
+        a[e[:, 1], e[:, 0]] = 1
+        return a
+
+    def get_adj_mat(self):
+        F, W, K = self.temporal_dim, self.window_size, self.num_kps
+        gap = np.abs(np.arange(F)[:, None] - np.arange(F)[None, :])
+        out = []
+        for w in range(K // W):
+            blocks = np.where(gap[:, :, None, None] == 0, self.get_adj(w),
+                              np.where(gap[:, :, None, None] == 1, np.eye(W), 0.0))
+            out.append(blocks.transpose(0, 2, 1, 3).reshape(F * W, F * W))
+        return np.array(out)
+
+    def get_model_params(self):
+        return (self.kp_dim, self.num_kps, self.temporal_dim, self.num_classes, self.embed_dim, self.pe,
+                self.depths, self.num_heads, self.window_size, self.ff_ratio, self.adj_mat, self.drop_rate,
+                self.attn_drop_rate, self.norm_layer, self.device)

@@ -99,7 +99,7 @@ def test_c_abi_rejects_bad_arguments_without_launching():
 
 @pytest.mark.skipif(not __import__("os").path.exists("/root/reference/hwgat/models/HWGATE.py"),
                     reason="reference tree only exists in the development container")
-@pytest.mark.parametrize("family", ["HWGATE", "HGATE"])
+@pytest.mark.parametrize("family", ["HWGATE", "HGATE", "WGATE"])
 def test_checkpoint_interchange_with_the_reference_class(family):
     """state_dict of this backend loads STRICTLY into the reference Model and vice versa
     (SURVEY 8b / 8f-4), for the headline model and the sibling HGATE (8f-3).
@@ -119,14 +119,14 @@ def test_checkpoint_interchange_with_the_reference_class(family):
     hp = getattr(hw, family + "Params")({"src_len": 64, "num_class": 11}, 2, torch.device("cpu"))
     assert [type(a) for a in hp.get_model_params()] == [type(a) for a in rp.get_model_params()]
     assert torch.equal(hp.adj_mat, rp.adj_mat)
-    mine = (hw.Model if family == "HWGATE" else hw.HGATEModel)(*hp.get_model_params())
+    mine = {"HWGATE": hw.Model, "HGATE": hw.HGATEModel, "WGATE": hw.WGATEModel}[family](*hp.get_model_params())
     sd_ref, sd_mine = ref.state_dict(), mine.state_dict()
     assert list(sd_ref.keys()) == list(sd_mine.keys())                       # same keys, same order
     assert all(sd_ref[k].shape == sd_mine[k].shape and sd_ref[k].dtype == sd_mine[k].dtype for k in sd_ref)
     mine.load_state_dict(sd_ref, strict=True)
     ref.load_state_dict(sd_mine, strict=True)
     for k in sd_ref:
-        if k.endswith("attn_mask") or k == "pos_encoder.pe":
+        if k.endswith("attn_mask") or k in ("pos_encoder.pe", "adj_mask"):
             assert torch.equal(sd_ref[k], sd_mine[k]), k                      # derived buffers are identical
     assert not mine.B.requires_grad and not ref.B.requires_grad
     assert sum(p.numel() for p in mine.parameters() if p.requires_grad) == \
