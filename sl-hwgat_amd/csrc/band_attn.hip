@@ -68,21 +68,24 @@ template <int NC> struct RowT { f32x4v c[NC]; };
 // column-operand tile: X[row = 4*g + r][c = 16*ct + (l&15)]  (B operand of a row contraction)
 template <int NC> struct ColT { float v[NC][4]; };
 
+// `base` is wave-uniform (SGPR pair), `off` a 32-bit per-lane element offset: the loads use the
+// "scalar base + vector offset" addressing form and need no 64-bit vector address arithmetic.
 template <typename T, int NC>
-__device__ __forceinline__ RowT<NC> load_row(const T* base, int64_t row_stride, int lr, int g, float mul) {
-    RowT<NC> t;
-    const T* p = base + lr * row_stride + 4 * g;
+__device__ __forceinline__ RowT<NC> load_row(const T* base, uint32_t off, float mul) {
+    RowT<NC> t;                                                  // off = (l&15) * row_stride + 4 * g
 #pragma unroll
-    for (int ch = 0; ch < NC; ++ch) t.c[ch] = ld4<T>(p + 16 * ch) * mul;
+    for (int ch = 0; ch < NC; ++ch) t.c[ch] = ld4<T>(base + off + 16 * ch) * mul;
     return t;
 }
 template <typename T, int NC>
-__device__ __forceinline__ ColT<NC> load_col(const T* base, int64_t row_stride, int lr, int g, float mul) {
-    ColT<NC> t;
+__device__ __forceinline__ ColT<NC> load_col(const T* base, int64_t row_stride, uint32_t off, float mul) {
+    ColT<NC> t;                                                  // off = 4 * g * row_stride + (l&15)
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < 4; ++r) {
+        const T* b = base + r * row_stride;
 #pragma unroll
-        for (int ct = 0; ct < NC; ++ct) t.v[ct][r] = ld1<T>(base + (4 * g + r) * row_stride + 16 * ct + lr) * mul;
+        for (int ct = 0; ct < NC; ++ct) t.v[ct][r] = ld1<T>(b + off + 16 * ct) * mul;
+    }
     return t;
 }
 template <int NC> __device__ __forceinline__ RowT<NC> zero_row() {
@@ -182,13 +185,14 @@ __device__ __forceinline__ uint32_t vis_q(uint64_t mrow, int g, bool has_prev, b
 }
 
 // =============================================================== forward
-template <typename T, int HD, int PF>
-__global__ __launch_bounds__(256) void band_attn_fwd_k(const T* __restrict__ qkv, T* __restrict__ o,
+template <typename T, int HD, int PF, int MINW>
+__global__ __launch_bounds__(256, MINW) void band_attn_fwd_k(const T* __restrict__ qkv, T* __restrict__ o,
                                                        const uint64_t* __restrict__ maskrows, BandGeom g,
                                                        int n_units) {
     constexpr int NC = HD / 16;
     const int lane = threadIdx.x & 63, lr = lane & 15, gq = lane >> 4;
-    const int u = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // the wave index is uniform; say so, so that unit decoding and all base pointers live in SGPRs
+    const int u = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (u >= n_units) return;
     const BandUnit un = decode_band(g, u);
     const int64_t rs = 3 * (int64_t)g.d;                         // qkv row stride (elements)
@@ -196,28 +200,30 @@ __global__ __launch_bounds__(256) void band_attn_fwd_k(const T* __restrict__ qkv
     T* ob = o + un.tok0 * (int64_t)g.d + un.head * HD;
     const int64_t fs = (int64_t)g.K * rs;                        // frame stride in qkv
     const uint64_t mrow = maskrows[un.w * 16 + lr];
+    const uint32_t roff = lr * (uint32_t)rs + 4 * gq, coff = 4 * gq * (uint32_t)rs + lr;   // per-lane offsets in qkv
+    const uint32_t ooff = 4 * gq * (uint32_t)g.d + lr;                                     // ... and in o
 
     // sliding window: K (row operand) and V (column operand) of frames f-1, f, f+1
     RowT<NC> kw[3];
     ColT<NC> vw[3];
     kw[0] = zero_row<NC>(); vw[0] = zero_col<NC>();
     if (un.f0 > 0) {
-        kw[0] = load_row<T, NC>(qb + (un.f0 - 1) * fs + g.d, rs, lr, gq, 1.0f);
-        vw[0] = load_col<T, NC>(qb + (un.f0 - 1) * fs + 2 * g.d, rs, lr, gq, 1.0f);
+        kw[0] = load_row<T, NC>(qb + (un.f0 - 1) * fs + g.d, roff, 1.0f);
+        vw[0] = load_col<T, NC>(qb + (un.f0 - 1) * fs + 2 * g.d, rs, coff, 1.0f);
     }
-    kw[1] = load_row<T, NC>(qb + un.f0 * fs + g.d, rs, lr, gq, 1.0f);
-    vw[1] = load_col<T, NC>(qb + un.f0 * fs + 2 * g.d, rs, lr, gq, 1.0f);
+    kw[1] = load_row<T, NC>(qb + un.f0 * fs + g.d, roff, 1.0f);
+    vw[1] = load_col<T, NC>(qb + un.f0 * fs + 2 * g.d, rs, coff, 1.0f);
 
     // prefetch ring: slot i holds Q of frame f+i and K, V of frame f+i+1
     RowT<NC> rq[PF], rk[PF];
     ColT<NC> rv[PF];
+    // loads are unconditional (a branch around a load makes the compiler drain the whole ring): frames
+    // past the clip re-read the last frame; such tiles are either never consumed or masked out by vis_q
     auto fill = [&](int i, int f) {                              // f = query frame of the slot
-        rq[i] = zero_row<NC>(); rk[i] = zero_row<NC>(); rv[i] = zero_col<NC>();
-        if (f < un.f1) rq[i] = load_row<T, NC>(qb + f * fs, rs, lr, gq, band_scale<HD>());
-        if (f < un.f1 && f + 1 < g.F) {
-            rk[i] = load_row<T, NC>(qb + (f + 1) * fs + g.d, rs, lr, gq, 1.0f);
-            rv[i] = load_col<T, NC>(qb + (f + 1) * fs + 2 * g.d, rs, lr, gq, 1.0f);
-        }
+        const int fq = min(f, g.F - 1), fk = min(f + 1, g.F - 1);
+        rq[i] = load_row<T, NC>(qb + fq * fs, roff, band_scale<HD>());
+        rk[i] = load_row<T, NC>(qb + fk * fs + g.d, roff, 1.0f);
+        rv[i] = load_col<T, NC>(qb + fk * fs + 2 * g.d, rs, coff, 1.0f);
     };
 #pragma unroll
     for (int i = 0; i < PF; ++i) fill(i, un.f0 + i);
@@ -226,11 +232,11 @@ __global__ __launch_bounds__(256) void band_attn_fwd_k(const T* __restrict__ qkv
 #pragma unroll
         for (int i = 0; i < PF; ++i) {
             const int f = fb + i;
+            const RowT<NC> q = rq[i];
+            kw[2] = rk[i];
+            vw[2] = rv[i];
+            fill(i, f + PF);
             if (f < un.f1) {
-                const RowT<NC> q = rq[i];
-                kw[2] = rk[i];
-                vw[2] = rv[i];
-                fill(i, f + PF);
                 f32x4v s[3], p[3];
 #pragma unroll
                 for (int t = 0; t < 3; ++t) s[t] = dot_rows<NC>(kw[t], q);     // s[t][r] = S[q = lr][key = 4g + r]
@@ -246,23 +252,24 @@ __global__ __launch_bounds__(256) void band_attn_fwd_k(const T* __restrict__ qkv
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int ct = 0; ct < NC; ++ct) st1<T>(of + (4 * gq + r) * (int64_t)g.d + 16 * ct + lr, oacc[ct][r]);
-                kw[0] = kw[1]; kw[1] = kw[2];
-                vw[0] = vw[1]; vw[1] = vw[2];
+                    for (int ct = 0; ct < NC; ++ct) st1<T>(of + r * (int64_t)g.d + ooff + 16 * ct, oacc[ct][r]);
             }
+            kw[0] = kw[1]; kw[1] = kw[2];
+            vw[0] = vw[1]; vw[1] = vw[2];
         }
     }
 }
 
 // =============================================================== backward
-template <typename T, int HD, int PF>
-__global__ __launch_bounds__(256) void band_attn_bwd_k(const T* __restrict__ qkv, const T* __restrict__ dO,
+template <typename T, int HD, int PF, int MINW>
+__global__ __launch_bounds__(256, MINW) void band_attn_bwd_k(const T* __restrict__ qkv, const T* __restrict__ dO,
                                                        T* __restrict__ dqkv,
                                                        const uint64_t* __restrict__ maskrows, BandGeom g,
                                                        int n_units) {
     constexpr int NC = HD / 16;
     const int lane = threadIdx.x & 63, lr = lane & 15, gq = lane >> 4;
-    const int u = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // the wave index is uniform; say so, so that unit decoding and all base pointers live in SGPRs
+    const int u = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (u >= n_units) return;
     const BandUnit un = decode_band(g, u);                       // backward units always span the whole clip
     const int64_t rs = 3 * (int64_t)g.d;
@@ -271,6 +278,8 @@ __global__ __launch_bounds__(256) void band_attn_bwd_k(const T* __restrict__ qkv
     const T* gb = dO + un.tok0 * (int64_t)g.d + un.head * HD;
     T* db = dqkv + un.tok0 * rs + un.head * HD;
     const uint64_t mrow = maskrows[un.w * 16 + lr];              // row of query joint lr
+    const uint32_t roff = lr * (uint32_t)rs + 4 * gq, coff = 4 * gq * (uint32_t)rs + lr;       // lane offsets in qkv / dqkv
+    const uint32_t groff = lr * (uint32_t)g.d + 4 * gq, gcoff = 4 * gq * (uint32_t)g.d + lr;  // ... in dO
     uint64_t mrow2[4];                                           // rows of query joints 4g + r (transposed tiles)
 #pragma unroll
     for (int r = 0; r < 4; ++r) mrow2[r] = maskrows[un.w * 16 + 4 * gq + r];
@@ -278,9 +287,9 @@ __global__ __launch_bounds__(256) void band_attn_bwd_k(const T* __restrict__ qkv
     struct KeyFrame { RowT<NC> k, v; ColT<NC> kc; };
     auto load_key = [&](int f) {
         KeyFrame x;
-        x.k = load_row<T, NC>(qb + f * fs + g.d, rs, lr, gq, 1.0f);
-        x.v = load_row<T, NC>(qb + f * fs + 2 * g.d, rs, lr, gq, 1.0f);
-        x.kc = load_col<T, NC>(qb + f * fs + g.d, rs, lr, gq, 1.0f);
+        x.k = load_row<T, NC>(qb + f * fs + g.d, roff, 1.0f);
+        x.v = load_row<T, NC>(qb + f * fs + 2 * g.d, roff, 1.0f);
+        x.kc = load_col<T, NC>(qb + f * fs + g.d, rs, coff, 1.0f);
         return x;
     };
     auto zero_key = [&]() {
@@ -302,16 +311,13 @@ __global__ __launch_bounds__(256) void band_attn_bwd_k(const T* __restrict__ qkv
     struct QFrame { RowT<NC> q, go; ColT<NC> qc, gc; };
     QFrame rq[PF];
     KeyFrame rk[PF];
-    auto fill = [&](int i, int f) {
-        rq[i].q = zero_row<NC>(); rq[i].go = zero_row<NC>(); rq[i].qc = zero_col<NC>(); rq[i].gc = zero_col<NC>();
-        rk[i] = zero_key();
-        if (f < g.F) {
-            rq[i].q = load_row<T, NC>(qb + f * fs, rs, lr, gq, band_scale<HD>());
-            rq[i].qc = load_col<T, NC>(qb + f * fs, rs, lr, gq, band_scale<HD>());
-            rq[i].go = load_row<T, NC>(gb + f * gs, g.d, lr, gq, 1.0f);
-            rq[i].gc = load_col<T, NC>(gb + f * gs, g.d, lr, gq, 1.0f);
-        }
-        if (f + 1 < g.F) rk[i] = load_key(f + 1);
+    auto fill = [&](int i, int f) {                              // unconditional, clamped (see the forward kernel)
+        const int fq = min(f, g.F - 1), fk = min(f + 1, g.F - 1);
+        rq[i].q = load_row<T, NC>(qb + fq * fs, roff, band_scale<HD>());
+        rq[i].qc = load_col<T, NC>(qb + fq * fs, rs, coff, band_scale<HD>());
+        rq[i].go = load_row<T, NC>(gb + fq * gs, groff, 1.0f);
+        rq[i].gc = load_col<T, NC>(gb + fq * gs, g.d, gcoff, 1.0f);
+        rk[i] = load_key(fk);
     };
 #pragma unroll
     for (int i = 0; i < PF; ++i) fill(i, i);
@@ -322,8 +328,8 @@ __global__ __launch_bounds__(256) void band_attn_bwd_k(const T* __restrict__ qkv
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int ct = 0; ct < NC; ++ct) {
-                st1<T>(row + (4 * gq + r) * rs + g.d + 16 * ct + lr, k[ct][r]);
-                st1<T>(row + (4 * gq + r) * rs + 2 * g.d + 16 * ct + lr, v[ct][r]);
+                st1<T>(row + r * rs + g.d + coff + 16 * ct, k[ct][r]);
+                st1<T>(row + r * rs + 2 * g.d + coff + 16 * ct, v[ct][r]);
             }
     };
 
@@ -331,10 +337,10 @@ __global__ __launch_bounds__(256) void band_attn_bwd_k(const T* __restrict__ qkv
 #pragma unroll
         for (int i = 0; i < PF; ++i) {
             const int f = fb + i;
+            const QFrame q = rq[i];
+            kw[2] = rk[i];
+            fill(i, f + PF);
             if (f < g.F) {
-                const QFrame q = rq[i];
-                kw[2] = rk[i];
-                fill(i, f + PF);
                 const bool hp = f > 0, hn = f + 1 < g.F;
                 // ---- orientation 1: lane = query joint lr, registers = key joints 4g + r
                 f32x4v s[3], p[3], ds[3];
@@ -364,7 +370,7 @@ __global__ __launch_bounds__(256) void band_attn_bwd_k(const T* __restrict__ qkv
                     for (int r = 0; r < 4; ++r)
 #pragma unroll
                         for (int ct = 0; ct < NC; ++ct)
-                            st1<T>(row + (4 * gq + r) * rs + 16 * ct + lr, acc[ct][r] * band_scale<HD>());
+                            st1<T>(row + r * rs + coff + 16 * ct, acc[ct][r] * band_scale<HD>());
                 }
                 // ---- orientation 2: lane = key joint lr, registers = query joints 4g + r
                 float m2[4], l2[4], d2[4];
@@ -439,9 +445,10 @@ extern "C" int hwgat_band_attn_fwd(const void* qkv, void* o, const uint64_t* mas
     if (units > 0x7fffffff) return HWGAT_ESHAPE;
     hipStream_t st = (hipStream_t)stream;
     const int blocks = (int)((units + 3) / 4);
+    // prefetch depth / occupancy: A/B on MI355X at B64 T128 K64 (fp32): PF 8 at 2 waves/SIMD 327 us, PF 4 at 3-4 waves/SIMD 295-302 us
 #define FWD(T)                                                                                                  \
-    if (hd == 16) band_attn_fwd_k<T, 16, 8><<<blocks, 256, 0, st>>>((const T*)qkv, (T*)o, maskrows, g, (int)units); \
-    else band_attn_fwd_k<T, 32, 4><<<blocks, 256, 0, st>>>((const T*)qkv, (T*)o, maskrows, g, (int)units);
+    if (hd == 32) band_attn_fwd_k<T, 32, 4, 1><<<blocks, 256, 0, st>>>((const T*)qkv, (T*)o, maskrows, g, (int)units); \
+    else band_attn_fwd_k<T, 16, 4, 3><<<blocks, 256, 0, st>>>((const T*)qkv, (T*)o, maskrows, g, (int)units);
     if (dtype == HWGAT_F32) { FWD(float) }
     else if (dtype == HWGAT_BF16) { FWD(bf16_t) }
     else return HWGAT_EDTYPE;
@@ -458,12 +465,15 @@ extern "C" int hwgat_band_attn_bwd(const void* qkv, const void* dO, void* dqkv, 
     if (units > 0x7fffffff) return HWGAT_ESHAPE;
     hipStream_t st = (hipStream_t)stream;
     const int blocks = (int)((units + 3) / 4);
-#define BWD(T)                                                                                                         \
-    if (hd == 16) band_attn_bwd_k<T, 16, 2><<<blocks, 256, 0, st>>>((const T*)qkv, (const T*)dO, (T*)dqkv, maskrows, g, (int)units); \
-    else band_attn_bwd_k<T, 32, 1><<<blocks, 256, 0, st>>>((const T*)qkv, (const T*)dO, (T*)dqkv, maskrows, g, (int)units);
+    // PF 2 at 1 wave/SIMD 644 us, PF 2 at 2-3 waves/SIMD 630 us, PF 1 at 2 waves/SIMD 619 us: all issue-bound alike
+#define BWD_ARGS(T) (const T*)qkv, (const T*)dO, (T*)dqkv, maskrows, g, (int)units
+#define BWD(T)                                                                                  \
+    if (hd == 32) band_attn_bwd_k<T, 32, 1, 1><<<blocks, 256, 0, st>>>(BWD_ARGS(T));            \
+    else band_attn_bwd_k<T, 16, 2, 2><<<blocks, 256, 0, st>>>(BWD_ARGS(T));
     if (dtype == HWGAT_F32) { BWD(float) }
     else if (dtype == HWGAT_BF16) { BWD(bf16_t) }
     else return HWGAT_EDTYPE;
 #undef BWD
+#undef BWD_ARGS
     HWGAT_LAUNCH_CHECK();
 }

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256, 2) void win_attn_fwd_k(const T* __restrict__ q
     constexpr int NLD = 32 / RPI;      // wave-wide loads per tile
     __shared__ __attribute__((aligned(16))) float smem[4 * 2 * 32 * LDW];
 
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // uniform: unit decoding in SGPRs
     const int lq = lane & 31, hh = lane >> 5;
     float* Qs = smem + wave * (2 * 32 * LDW);
     float* Ks = Qs + 32 * LDW;
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void win_attn_bwd_k(const T* __restr
     constexpr int PER_WAVE = 4 * 32 * LDW + EXTRA;
     __shared__ __attribute__((aligned(16))) float smem[WAVES * PER_WAVE];
 
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // uniform: unit decoding in SGPRs
     const int lq = lane & 31, hh = lane >> 5;
     float* Qs = smem + wave * PER_WAVE;
     float* Ks = Qs + 32 * LDW;

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""time the WGATE band-attention kernels alone"""
+import importlib, os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+hw = importlib.import_module("sl-hwgat_amd")
+HF = hw.functional
+from oracle import wgat_oracle as OW
+B, F, nW, nH, hd = 64, 128, 4, 8, 16
+dt = torch.bfloat16 if len(sys.argv) > 1 and sys.argv[1] == "bf16" else torch.float32
+d, K = nH * hd, nW * 16
+dev = "cuda:0"
+qkv = torch.randn(B, F, K, 3 * d, device=dev).to(dt)
+do = torch.randn(B, F, K, d, device=dev).to(dt)
+o = torch.empty_like(do)
+dq = torch.empty_like(qkv)
+rows = HF.band_mask_rows(OW.band_adjacency(F, nW), F).to(dev)
+E = B * F * K * d * qkv.element_size()
+for name, fn, mult in (("fwd", lambda: HF.attn_fwd("band", qkv, o, rows, None, nH, False), 4),
+                       ("bwd", lambda: HF.attn_bwd("band", qkv, do, dq, rows, None, nH, False), 7)):
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / 20 * 1e3
+    print(f"{dt} {name}: {us:8.1f} us  {mult * E / us / 1e6:7.2f} TB/s")
