@@ -214,11 +214,13 @@ def main():
         # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 correction + WRITE_SIZE,
         # separate passes; profiles/r01_attn_pmc_traffic.json) -- only valid for the shape they were taken on
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_attn_pmc_traffic.json")) as fh:
+            fname = "r01k_sibling_attn_pmc_traffic.json" if (hgate or wgate) else "r01_attn_pmc_traffic.json"
+            with open(os.path.join(ROOT, "profiles", fname)) as fh:
                 pmc = json.load(fh)
-            if pmc["E_bytes"] == E * itemsize and args.dtype == "f32":
-                for name in kern:
-                    kern[name]["traffic"] = pmc[name]["traffic_bytes_per_launch"]
+            for name in kern:
+                rec = pmc.get(name + "_1seg", pmc.get(name))          # band fwd: the shipped 1-segment geometry
+                if rec and rec.get("E_bytes", pmc.get("E_bytes")) == E * itemsize and args.dtype == "f32":
+                    kern[name]["traffic"] = rec["traffic_bytes_per_launch"]
         except (OSError, KeyError):
             pass
         # linears: useful flops per step (fwd + dX + dW = 3 x 16*E*d_i per block) against the dense MFMA peak

@@ -437,7 +437,8 @@ extern "C" int hwgat_band_attn_fwd(const void* qkv, void* o, const uint64_t* mas
     // enough wavefronts to fill the chip: split the clip into frame segments (1 halo frame of K, V each)
     const int64_t base_units = (int64_t)B * nW * nH;
     int n_seg = 1;
-    while (base_units * n_seg < 256 * 16 && F / (n_seg * 2) >= 8) n_seg *= 2;
+    // (at B64 T128: 2048 / 4096 / 8192 waves run in 296 / 298 / 334 us and fetch 1.19 / 1.33 / - x the algorithmic bytes)
+    while (base_units * n_seg < 256 * 8 && F / (n_seg * 2) >= 8) n_seg *= 2;
     const int seg = (F + n_seg - 1) / n_seg;
     n_seg = (F + seg - 1) / seg;
     BandGeom g{F, nW * 16, nW, nH, nH * hd, seg, n_seg};
