@@ -90,12 +90,16 @@ class _FusedBlock(torch.autograd.Function):
         B, F, K, d = x.shape
         dt = x.dtype
         dout = dout.contiguous()
-        z = lambda t: torch.zeros_like(t)
-        dn1w, dn1b, dn2w, dn2b = z(n1w), z(n1b), z(n2w), z(n2b)
-        dwqkv, dwp, dw1, dw2 = z(wqkv), z(wp), z(w1), z(w2)
-        dbqkv = torch.zeros(3 * d, device=x.device)
-        dbp, db2 = torch.zeros(d, device=x.device), torch.zeros(d, device=x.device)
-        db1 = torch.zeros(w1.shape[0], device=x.device)
+        # all 12 parameter gradients are accumulated into (split-M atomics, LN column sums): one flat
+        # zero-filled buffer and views of it instead of 12 fill launches
+        hid = w1.shape[0]
+        sizes = [d, d, d, d, 3 * d * d, d * d, hid * d, d * hid, 3 * d, d, d, hid]
+        flat = torch.zeros(sum(sizes), device=x.device, dtype=torch.float32)
+        parts = torch.split(flat, sizes)
+        dn1w, dn1b, dn2w, dn2b = parts[0], parts[1], parts[2], parts[3]
+        dwqkv, dwp = parts[4].view(3 * d, d), parts[5].view(d, d)
+        dw1, dw2 = parts[6].view(hid, d), parts[7].view(d, hid)
+        dbqkv, dbp, db2, db1 = parts[8], parts[9], parts[10], parts[11]
 
         dwq = _DwQueue(x.device, OVERLAP_DW)
         # ---- FFN branch: out = y + drop3(u W2^T + b2), u = drop2(gelu(h1)), h1 = LN2(y) W1^T + b1
@@ -113,6 +117,8 @@ class _FusedBlock(torch.autograd.Function):
         HF.attn_bwd(kind, qkv, d_o, dqkv, bits, thr, n_heads, shifted)
         dwq.run(lambda: HF.linear_tn(dqkv, x, dwqkv, dbqkv, ln=(m1, r1, n1w, n1b)))
         d_xn = HF.linear_nt(dqkv, HF.transpose(wqkv, dt), None, epi=HF.EPI_NONE, out=d_o)
+        # (the first block's input comes from the parameter-free embedding: its dx is still produced because
+        # dgamma / dbeta of norm1 fall out of the same LayerNorm-backward pass)
         dx = HF.ln_backward(d_xn, x, m1, r1, n1w, d_y, dn1w, dn1b)
         dwq.join()        # every temporary above stays referenced until here, so the allocator cannot recycle it early
         return (dx, None, dn1w, dn1b, dwqkv, dbqkv, dwp, dbp, dn2w, dn2b, dw1, db1, dw2, db2, None)
