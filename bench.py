@@ -117,6 +117,13 @@ def main():
     ap.add_argument("--eval-mode", action="store_true", help="deterministic fwd+bwd (no dropout / attention drop)")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE JSON line: native libraries (RCCL prints a version banner on process-group
+    # init) write to file descriptor 1 directly, so fd 1 is pointed at stderr for the whole run and the
+    # result line goes to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -267,7 +274,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline and args.config != 5:
             out["cpu_baseline"] = cpu_baseline_wgate() if wgate else cpu_baseline(hgate=hgate)
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.destroy_process_group()
 
