@@ -131,3 +131,47 @@ def test_checkpoint_interchange_with_the_reference_class(family):
     assert not mine.B.requires_grad and not ref.B.requires_grad
     assert sum(p.numel() for p in mine.parameters() if p.requires_grad) == \
         sum(p.numel() for p in ref.parameters() if p.requires_grad)
+
+
+def test_sibling_mask_rows_on_cpu():
+    """host-side mask compaction of the sibling models (no GPU needed): HGATE block bits decode back to the
+    adjacency; WGATE band rows decode back to the three 16x16 blocks and malformed adjacencies are rejected"""
+    from oracle import hgat_oracle as OH, wgat_oracle as OW
+    HF = hw.functional
+    adj = OH.block_adjacency()
+    bits = HF.blk_mask_bits(adj, 29).numpy().astype(np.int64) & 0xFFFFFFFF
+    assert bits.shape == (2, 64, 2)
+    for tq in range(2):
+        for jq in range(29):
+            for tk in range(2):
+                row = [(int(bits[0, tq * 32 + jq, tk]) >> j) & 1 for j in range(32)]
+                assert row[:29] == [int(v) for v in adj[tq * 29 + jq, tk * 29:tk * 29 + 29]] and not any(row[29:])
+                last = int(bits[1, tq * 32 + jq, tk])
+                assert last == (int(bits[0, tq * 32 + jq, tk]) if tq == tk else 0)
+    assert not bits[:, 29:32].any() and not bits[:, 61:64].any()              # pad query slots
+    with pytest.raises(ValueError):
+        HF.blk_mask_bits(adj * 0.5, 29)
+    with pytest.raises(ValueError):
+        HF.blk_mask_bits(torch.ones(70, 70), 35)
+
+    T, nW = 5, 2
+    band = OW.band_adjacency(T, nW)
+    rows = HF.band_mask_rows(band, T)
+    assert rows.shape == (nW, 16) and rows.dtype == torch.int64
+    pa = OW.part_adjacency()
+    for i in range(16):
+        r = int(rows[1, i])
+        assert [(r >> j) & 1 for j in range(16)] == [int(i == j) for j in range(16)]                 # previous frame
+        assert [(r >> (16 + j)) & 1 for j in range(16)] == [int(v) for v in pa[i]]                   # same frame
+        assert [(r >> (32 + j)) & 1 for j in range(16)] == [int(i == j) for j in range(16)]          # next frame
+    assert HF.band_mask_rows(OW.band_adjacency(1, 1), 1).shape == (1, 16)                            # T = 1: no neighbours
+    far = band.clone()
+    far[0, 0, 3 * 16] = 1
+    with pytest.raises(NotImplementedError):
+        HF.band_mask_rows(far, T)
+    no_diag = band.clone()
+    no_diag[1, 2 * 16 + 4, 2 * 16:3 * 16] = 0
+    with pytest.raises(NotImplementedError):
+        HF.band_mask_rows(no_diag, T)
+    with pytest.raises(ValueError):
+        HF.band_mask_rows(band, T + 1)
