@@ -103,9 +103,10 @@ __global__ __launch_bounds__(128, 2) void blk_attn_fwd_k(const T* __restrict__ q
                                                       int n_units) {
     using C = BlkCfg<T, HD>;
     constexpr int LDW = C::LDW, NT = C::NT, NLD = C::NLD, RPI = C::RPI, TILE = C::TILE;
-    __shared__ __attribute__((aligned(16))) float smem[4 * TILE];      // Q0 Q1 K0 K1
+    __shared__ __attribute__((aligned(16))) float smem[6 * TILE];      // Q0 Q1 K0 K1 V0 V1
     float* Qs = smem;
     float* Ks = smem + 2 * TILE;
+    float* Vs = smem + 4 * TILE;
 
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, lq = lane & 31, hh = lane >> 5;
     const int crow_l = lane / C::CPR, ccol = (lane % C::CPR) * C::EPV;
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(128, 2) void blk_attn_fwd_k(const T* __restrict__ q
     int u = blockIdx.x;
     if (u >= n_units) return;
 
-    u32x4 qr[NLD], kr[NLD];
+    u32x4 qr[NLD], kr[NLD], vr[NLD];
     auto issue_qk = [&](const BUnit& un) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
@@ -124,33 +125,24 @@ __global__ __launch_bounds__(128, 2) void blk_attn_fwd_k(const T* __restrict__ q
             const T* p = qkv + ((w ? un.base[1] : un.base[0]) + (ok ? j : g.KJ - 1)) * row3d + un.head * HD + ccol;
             const u32x4 a = *reinterpret_cast<const u32x4*>(p);
             const u32x4 b = *reinterpret_cast<const u32x4*>(p + g.d);
+            const u32x4 c = *reinterpret_cast<const u32x4*>(p + 2 * g.d);
             qr[i] = ok ? a : zero4;
             kr[i] = ok ? b : zero4;
+            vr[i] = ok ? c : zero4;
         }
     };
     BUnit cur = decode_bunit(g, u);
     issue_qk(cur);
 
     for (; u < n_units; u += gridDim.x) {
-        // -- stage Q (pre-scaled, HGATE.py:91) and K
+        // -- stage Q (pre-scaled, HGATE.py:91), K and V: every element is fetched by exactly one wave
+        //    (both waves pulling V into registers re-read 19 % of the bytes from HBM: PMC)
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int off = (w * 32 + i * RPI + crow_l) * LDW + ccol;
             chunk<T>::to_lds(Qs + off, qr[i], qk_scale<HD>());
             chunk<T>::to_lds(Ks + off, kr[i], 1.0f);
-        }
-        // -- V straight into the MFMA B-operand layout (pad rows = 0)
-        float v[2][16][NT];
-        {
-            const T* vb = qkv + 2 * g.d + cur.head * HD + lq * NT;
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) v[kt][r][nt] = 0.f;
-                    if (crow(r, hh) < g.KJ) load_nt<T, NT>(vb + (cur.base[kt] + crow(r, hh)) * row3d, v[kt][r]);
-                }
+            chunk<T>::to_lds(Vs + off, vr[i], 1.0f);
         }
         const uint32_t mb0 = maskbits[(cur.mrow + w * 32 + lq) * 2];
         const uint32_t mb1 = maskbits[(cur.mrow + w * 32 + lq) * 2 + 1];
@@ -170,17 +162,8 @@ __global__ __launch_bounds__(128, 2) void blk_attn_fwd_k(const T* __restrict__ q
         masked_softmax64(s, p, mb0, mb1, hh, g.KJ);
 
         f32x16 oacc[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) oacc[nt][i] = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    oacc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(p[kt][r], v[kt][r][nt], oacc[nt], 0, 0, 0);
+        tile_ay<HD, LDW, true>(p[0], Vs, lq, hh, oacc);           // P fed back as the A operand, V in the B layout from LDS
+        tile_ay<HD, LDW, false>(p[1], Vs + TILE, lq, hh, oacc);
 
         // lane (c=lq, hh), reg r -> O[q = crow(r,hh)][c*NT + nt]
         T* ob = o + ohead * HD + lq * NT;
@@ -393,7 +376,7 @@ constexpr int LDS_PER_CU = 160 * 1024;
 
 template <typename T, int HD>
 int launch_bfwd(const void* qkv, void* o, const uint32_t* mb, BlkGeom g, int n_units, hipStream_t st) {
-    constexpr int per_cu = LDS_PER_CU / (4 * BlkCfg<T, HD>::TILE * 4);
+    constexpr int per_cu = LDS_PER_CU / (6 * BlkCfg<T, HD>::TILE * 4);
     const int blocks = min(n_units, 256 * (per_cu > 8 ? 8 : per_cu));
     blk_attn_fwd_k<T, HD><<<blocks, 128, 0, st>>>((const T*)qkv, (T*)o, mb, g, n_units);
     HWGAT_LAUNCH_CHECK();
