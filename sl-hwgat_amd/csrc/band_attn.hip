@@ -192,8 +192,9 @@ __global__ __launch_bounds__(256, MINW) void band_attn_fwd_k(const T* __restrict
     constexpr int NC = HD / 16;
     const int lane = threadIdx.x & 63, lr = lane & 15, gq = lane >> 4;
     // the wave index is uniform; say so, so that unit decoding and all base pointers live in SGPRs
-    const int u = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (u >= n_units) return;
+    const int u_raw = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool live = u_raw < n_units;                           // tail waves shadow the last unit (no stores): every
+    const int u = live ? u_raw : n_units - 1;                    // wave of a workgroup reaches the per-group barrier
     const BandUnit un = decode_band(g, u);
     const int64_t rs = 3 * (int64_t)g.d;                         // qkv row stride (elements)
     const T* qb = qkv + un.tok0 * rs + un.head * HD;
@@ -228,7 +229,10 @@ __global__ __launch_bounds__(256, MINW) void band_attn_fwd_k(const T* __restrict
 #pragma unroll
     for (int i = 0; i < PF; ++i) fill(i, un.f0 + i);
 
-    for (int fb = un.f0; fb < un.f1; fb += PF) {
+    for (int fb = un.f0; fb < un.f0 + g.seg; fb += PF) {
+        // the 4 waves of a workgroup are neighbouring heads of one (clip, window): keep them within PF frames of
+        // each other so that the two heads sharing a 128-byte line touch it while it is still cached
+        __syncthreads();
 #pragma unroll
         for (int i = 0; i < PF; ++i) {
             const int f = fb + i;
@@ -236,7 +240,7 @@ __global__ __launch_bounds__(256, MINW) void band_attn_fwd_k(const T* __restrict
             kw[2] = rk[i];
             vw[2] = rv[i];
             fill(i, f + PF);
-            if (f < un.f1) {
+            if (f < un.f1 && live) {
                 f32x4v s[3], p[3];
 #pragma unroll
                 for (int t = 0; t < 3; ++t) s[t] = dot_rows<NC>(kw[t], q);     // s[t][r] = S[q = lr][key = 4g + r]
@@ -269,8 +273,9 @@ __global__ __launch_bounds__(256, MINW) void band_attn_bwd_k(const T* __restrict
     constexpr int NC = HD / 16;
     const int lane = threadIdx.x & 63, lr = lane & 15, gq = lane >> 4;
     // the wave index is uniform; say so, so that unit decoding and all base pointers live in SGPRs
-    const int u = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (u >= n_units) return;
+    const int u_raw = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool live = u_raw < n_units;                           // tail waves shadow the last unit without storing
+    const int u = live ? u_raw : n_units - 1;
     const BandUnit un = decode_band(g, u);                       // backward units always span the whole clip
     const int64_t rs = 3 * (int64_t)g.d;
     const int64_t fs = (int64_t)g.K * rs, gs = (int64_t)g.K * g.d;
@@ -334,13 +339,14 @@ __global__ __launch_bounds__(256, MINW) void band_attn_bwd_k(const T* __restrict
     };
 
     for (int fb = 0; fb < g.F; fb += PF) {
+        __syncthreads();                                         // neighbouring heads stay within PF frames (see forward)
 #pragma unroll
         for (int i = 0; i < PF; ++i) {
             const int f = fb + i;
             const QFrame q = rq[i];
             kw[2] = rk[i];
             fill(i, f + PF);
-            if (f < g.F) {
+            if (f < g.F && live) {
                 const bool hp = f > 0, hn = f + 1 < g.F;
                 // ---- orientation 1: lane = query joint lr, registers = key joints 4g + r
                 f32x4v s[3], p[3], ds[3];
@@ -406,7 +412,7 @@ __global__ __launch_bounds__(256, MINW) void band_attn_bwd_k(const T* __restrict
             }
         }
     }
-    store_key(g.F - 1, dk[0], dv[0]);                            // after the rotation the last key frame sits in slot 0
+    if (live) store_key(g.F - 1, dk[0], dv[0]);                  // after the rotation the last key frame sits in slot 0
 }
 
 __global__ void mfma16_probe_k(const float* a, const float* b, float* out) {
