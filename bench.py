@@ -252,6 +252,14 @@ def main():
         roof["kernel"] = ("blk_attn_bwd_k (fused block graph-attention backward, HGATE)" if hgate
                           else "band_attn_bwd_k (fused band graph-attention backward, WGATE)" if wgate
                           else "win_attn_bwd_k (fused window graph-attention backward)")
+        # SURVEY 8(d) "secondary" roofline of the whole step: fwd+bwd flops (linears 16*sum_d*E + dense attention
+        # 128*E per block, x3 for fwd + dX + dW) against the dense MFMA peak of the compute dtype -- the bound
+        # that binds config 2 in fp32 (the attention kernels above are the HBM-bound part north_star names)
+        n_blocks = 8
+        flops_clip = 3.0 * (16.0 * sum_d + 128.0 * n_blocks) * (c["T"] * K * c["d0"])
+        e2e = world * c["B"] * args.steps / elapsed * flops_clip
+        roof_e2e = {"bound": "mfma", "achieved": round(e2e / 1e12, 1), "peak": peak / 1e12, "unit": "TFLOP/s",
+                    "frac": round(e2e / (world * peak), 4), "flops_per_clip": flops_clip}
         out = {
             "metric": "clips/sec fwd+bwd at B=64 T=128 J=67; %HBM roofline; 1->8 GPU scaling",
             "value": round(world * c["B"] * args.steps / elapsed, 2), "unit": "clips/s",
@@ -267,7 +275,7 @@ def main():
                                    + ("eval-mode" if args.eval_mode else "train-mode drop 0.1")
                                    + (f", micro-batch {args.micro_batch}" if args.micro_batch else ""),
                        "global_batch": world * c["B"], "parallelism": f"dp{world}"},
-            "roofline": roof,
+            "roofline": roof, "roofline_end_to_end": roof_e2e,
             "kernels": kern, "other_hip_entry_points": others,
             "hip_kernel_ms_per_step": round(hip_ms / args.steps, 3),
             "loss": round(loss, 4),
