@@ -115,6 +115,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true", help="skip the per-launch HIP events (A/B runs)")
     ap.add_argument("--eval-mode", action="store_true", help="deterministic fwd+bwd (no dropout / attention drop)")
+    ap.add_argument("--from-host", action="store_true",
+                    help="feed every step from host samples through collate.PinnedBatcher (pinned staging + async H2D): "
+                         "the PCIe-inclusive rate DESIGN.md quotes; never the headline")
     args = ap.parse_args()
 
     # stdout carries exactly ONE JSON line: native libraries (RCCL prints a version banner on process-group
@@ -185,13 +188,26 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.from_host:
+        batcher = import_module("sl-hwgat_amd.collate").PinnedBatcher(c["B"], (c["T"], c["J"], c["C"]), dev)
+        xs, ys = x.cpu(), y.cpu()
+        samples = [(xs[i], int(ys[i])) for i in range(c["B"])]          # what a Dataset hands the collate_fn
+
+        def run_step():
+            xb, yb = batcher.collate(samples)
+            step(xb, yb)
+            batcher.release()
+    else:
+        def run_step():
+            step(x, y)
+
     for _ in range(args.warmup):
-        step(x, y)
+        run_step()
     barrier()
     HF.TIMERS = None if args.no_kernel_timers else {}
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(x, y)
+        run_step()
     barrier()
     elapsed = time.perf_counter() - t0
     timers = HF.timers_summary()
@@ -265,7 +281,8 @@ def main():
             "value": round(world * c["B"] * args.steps / elapsed, 2), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+            "data": "synthetic" + (", host-fed" if args.from_host else ""),
             "config": {"workload": ("sibling model HGATE at the headline shape" if hgate else
                                     "sibling model WGATE at the headline shape" if wgate else
                                     f"BASELINE configs[{ {2: 1, 3: 2, 5: 4}[args.config] }]")
@@ -273,7 +290,9 @@ def main():
                                    f"B={c['B']}/GPU T={c['T']} J={c['J']}->K={K} C={c['C']} "
                                    f"d_model={c['d0']} " + ("8 blocks" if wgate else "depths[2,2,4]") + f" classes={c['nc']}, "
                                    + ("eval-mode" if args.eval_mode else "train-mode drop 0.1")
-                                   + (f", micro-batch {args.micro_batch}" if args.micro_batch else ""),
+                                   + (f", micro-batch {args.micro_batch}" if args.micro_batch else "")
+                                   + (", inputs collated from host samples every step (PCIe-inclusive, not the headline)"
+                                      if args.from_host else ""),
                        "global_batch": world * c["B"], "parallelism": f"dp{world}"},
             "roofline": roof, "roofline_end_to_end": roof_e2e,
             "kernels": kern, "other_hip_entry_points": others,
