@@ -160,7 +160,8 @@ int hwgat_merge(const void* in, void* out, int B, int F, int K, int d, int inver
 /* ---- a-6/a-7/a-8: fp32 Linear layers on f32 MFMA with fused elementwise work.
  * Replaces nn.Linear (HWGATE.py:86,115,131,134) + bias + GELU (:132) + Dropout
  * (:116,:133,:135) + residual adds (:217,:219) forward, and their dX backward.
- *   C[M,N] = pro(A)[M,K] . W[N,K]^T, all fp32 row-major; M % 128 == N % 128 == K % 32 == 0.
+ *   C[M,N] = pro(A)[M,K] . W[N,K]^T, all fp32 row-major; N % 128 == K % 32 == 0, any M >= 1
+ *   (a ragged last 128-row block clamps its loads to row M-1 and guards its stores).
  *   pro: 0 none | 1 LayerNorm: (A-mean[m])*rstd[m]*gamma[k]+beta[k] | 2 dropout mask on A
  *        (keep-scale 1/(1-pro_p), element index m*K+k, seed pro_seed)
  *   epi: 0  C = acc + bias
@@ -176,7 +177,7 @@ int hwgat_linear_nt_f32(const float* A, const float* W, const float* bias, float
 
 /* weight/bias gradient: dW[N,K] += dropmask(A)[M,N]^T . ln(B)[M,K] ; db[N] += colsum(dropmask(A))
  * (db may be NULL).  Accumulates with fp32 atomics across M slices: caller provides zeroed
- * (or to-be-accumulated-into) dW/db.  M % 32 == N % 128 == K % 128 == 0.  pro_p == 0: no mask.
+ * (or to-be-accumulated-into) dW/db.  N % 128 == K % 128 == 0, any M >= 1.  pro_p == 0: no mask.
  * mean != NULL: B is LayerNorm-ed on the fly, (B-mean[m])*rstd[m]*gamma[k]+beta[k]. */
 int hwgat_linear_tn_f32(const float* A, const float* B, float* dW, float* db, int64_t M, int N, int K,
                         uint32_t pro_seed, float pro_p, const float* mean, const float* rstd,

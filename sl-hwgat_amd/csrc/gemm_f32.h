@@ -8,6 +8,7 @@ struct NtArgs {
     const float* mean; const float* rstd; const float* gamma; const float* beta;
     int64_t M; int N, K;
     uint32_t pro_seed, epi_seed; float pro_p, epi_p;
+    int64_t row0;          // RAGGED tail launches: global index of this launch's first row (dropout hash)
 };
 
 
@@ -18,6 +19,7 @@ struct TnArgs {
     int64_t M; int N, K;
     int n_split; int64_t rows_per_split;
     uint32_t pro_seed; float pro_p;
+    int64_t row0;          // see NtArgs
 };
 
 

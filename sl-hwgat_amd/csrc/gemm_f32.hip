@@ -44,7 +44,11 @@ using NtSmall = TileCfg<2, 2, 2, 2>;
 using NtBig = TileCfg<4, 2, 2, 4, 32, 1>;
 using NtK16 = TileCfg<2, 2, 2, 2, 16, 3>;                      // 41 KB LDS -> 3 blocks / CU
 
-template <int PRO, int EPI, typename C>
+// RAGGED: the launch covers the last M % 128 rows of a token count that is not a multiple of the tile
+// (HGATE: M = B*F*29).  It is a separate instantiation so that the bulk launch stays exactly the code
+// measured in DESIGN.md: loads clamp to the last row, stores are guarded, and dropout masks are hashed
+// with the global row index (p.row0 = first row of this launch in the full matrix).
+template <int PRO, int EPI, typename C, bool RAGGED = false>
 __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt_k(NtArgs p) {
     constexpr int BM = C::BM, BN = C::BN, TMW = C::TMW, TNW = C::TNW, PA = C::PA, PW = C::PW, RPP = C::RPP;
     constexpr int BK = C::BK, LDT = C::LDT;
@@ -53,7 +57,9 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt
     const int lq = lane & 31, hh = lane >> 5;
     const int wm = wave / C::WN, wn = wave % C::WN;
     const int tiles_n = p.N / BN;
-    const int n_tiles = (int)(p.M / BM) * tiles_n;
+    const int row_blocks = RAGGED ? (int)((p.M + BM - 1) / BM) : (int)(p.M / BM);
+    const int n_tiles = row_blocks * tiles_n;
+    const int64_t m_last = p.M - 1;
     const int n_slab = p.K / BK;
     const int lrow = tid / C::TPR, lc4 = (tid % C::TPR) * 4;   // this thread stages rows lrow + RPP*i, floats lc4..lc4+3
     const uint32_t pro_th = drop_thresh(p.pro_p);
@@ -65,7 +71,6 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt
 
     // XCD-aware tile order: blocks b, b+8, b+16, ... share an XCD (and its L2); give them the
     // n-tiles of ONE row block of A, so A streams from HBM once and is re-read from L2.
-    const int row_blocks = (int)(p.M / BM);
     const int swz_tiles = (row_blocks / 8) * 8 * tiles_n;
     auto tile_origin = [&](int t, int64_t& m0, int& n0) {
         int rb, nt;
@@ -84,7 +89,8 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt
         const int k0 = slab * BK + lc4;
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
-            const int64_t row = m0 + lrow + RPP * i;
+            int64_t row = m0 + lrow + RPP * i;
+            if constexpr (RAGGED) row = row < m_last ? row : m_last;
             ra[i] = *reinterpret_cast<const f32x4*>(p.A + row * p.K + k0);
             if constexpr (PRO == PRO_LN) {
                 if (new_tile) { ln_mean[i] = p.mean[row]; ln_rstd[i] = p.rstd[row]; }
@@ -108,7 +114,7 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt
             if constexpr (PRO == PRO_LN) {
                 a = (a - ln_mean[i]) * (ln_rstd[i] * ln_g) + ln_b;
             } else if constexpr (PRO == PRO_DROP) {
-                if (pro_th) a *= drop_keep4(p.pro_seed, (uint64_t)(m0 + lrow + RPP * i) * p.K + k0, pro_th, pro_sc);
+                if (pro_th) a *= drop_keep4(p.pro_seed, (uint64_t)((RAGGED ? p.row0 : 0) + m0 + lrow + RPP * i) * p.K + k0, pro_th, pro_sc);
             }
             *reinterpret_cast<f32x4*>(As + (lrow + RPP * i) * LDT + lc4) = a;
         }
@@ -201,11 +207,13 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt
 #pragma unroll 2
                     for (int ps = 0; ps < NPS; ++ps) {
                         const int rr = ps * RPS + er;
-                        const int64_t off = (m0 + wm * (TMW * 32) + i * 32 + rr) * p.N + col;
+                        const int64_t grow = m0 + wm * (TMW * 32) + i * 32 + rr;
+                        if constexpr (RAGGED) { if (grow > m_last) continue; }
+                        const int64_t off = grow * p.N + col;
                         f32x4 v = *reinterpret_cast<const f32x4*>(stg + rr * SLD + ec) + bv;
                         f32x4 dk = {1.f, 1.f, 1.f, 1.f};
                         if constexpr (EPI == EPI_BIAS_DROP_RES || EPI == EPI_BIAS_GELU_DROP || EPI == EPI_GELU_BWD) {
-                            if (epi_th) dk = drop_keep4(p.epi_seed, (uint64_t)off, epi_th, epi_sc);
+                            if (epi_th) dk = drop_keep4(p.epi_seed, (uint64_t)(off + (RAGGED ? p.row0 * p.N : 0)), epi_th, epi_sc);
                         }
                         if constexpr (EPI == EPI_BIAS_DROP_RES) {
                             v = *reinterpret_cast<const f32x4*>(p.res + off) + v * dk;
@@ -246,7 +254,8 @@ using TnK16 = TileCfg<2, 2, 2, 2, 16, 3>;                      // 32 KB LDS -> 3
 // accumulator-register traffic per flop) instead of v_mfma_f32_32x32x2_f32.  Measured on MI355X:
 // +2..4 % at K <= 256, -2 % at K = 512 -- not the source of the library's 0.91 vs our 0.82 MFMA
 // utilisation; kept behind HWGAT_GEMM_TILE=m for A/B runs.
-template <int PRO, bool BLN, typename C, bool MF16 = false>
+// RAGGED: launch over the last M % 32 rows (see gemm_nt_k): one partial stage, rows >= M count as zero.
+template <int PRO, bool BLN, typename C, bool MF16 = false, bool RAGGED = false>
 __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_tn_k(TnArgs p) {
     constexpr int TM = C::BK;
     constexpr int BT = C::BM;                                  // == C::BN
@@ -270,7 +279,8 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_tn
     const int64_t r_begin = (int64_t)split * p.rows_per_split;
     const int64_t r_end = r_begin + p.rows_per_split < p.M ? r_begin + p.rows_per_split : p.M;
     if (r_begin >= r_end) return;
-    const int n_it = (int)((r_end - r_begin) / TM);
+    const int n_it = RAGGED ? (int)((r_end - r_begin + TM - 1) / TM) : (int)((r_end - r_begin) / TM);
+    const int64_t m_last = p.M - 1;
 
     const int lrow = tid / TPR, lc4 = (tid % TPR) * 4;         // rows lrow + RPP*i, floats lc4..lc4+3
     const uint32_t pro_th = drop_thresh(p.pro_p);
@@ -288,9 +298,11 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_tn
         const int64_t r0 = r_begin + (int64_t)it * TM + lrow;
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
-            ra[i] = *reinterpret_cast<const f32x4*>(p.A + (r0 + RPP * i) * p.N + n0 + lc4);
-            rb[i] = *reinterpret_cast<const f32x4*>(p.B + (r0 + RPP * i) * p.K + k0 + lc4);
-            if constexpr (BLN) { bm[i] = p.mean[r0 + RPP * i]; bs[i] = p.rstd[r0 + RPP * i]; }
+            int64_t row = r0 + RPP * i;
+            if constexpr (RAGGED) row = row < m_last ? row : m_last;
+            ra[i] = *reinterpret_cast<const f32x4*>(p.A + row * p.N + n0 + lc4);
+            rb[i] = *reinterpret_cast<const f32x4*>(p.B + row * p.K + k0 + lc4);
+            if constexpr (BLN) { bm[i] = p.mean[row]; bs[i] = p.rstd[row]; }
         }
     };
     auto commit = [&](int buf, int it) {
@@ -301,8 +313,9 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_tn
         for (int i = 0; i < NP; ++i) {
             f32x4 a = ra[i], b = rb[i];
             if constexpr (PRO == PRO_DROP)
-                a *= drop_keep4(p.pro_seed, (uint64_t)(r0 + RPP * i) * p.N + n0 + lc4, pro_th, pro_sc);
+                a *= drop_keep4(p.pro_seed, (uint64_t)((RAGGED ? p.row0 : 0) + r0 + RPP * i) * p.N + n0 + lc4, pro_th, pro_sc);
             if constexpr (BLN) b = (b - bm[i]) * bs[i] * lg + lb;
+            if constexpr (RAGGED) { if (r0 + RPP * i > m_last) a = f32x4{0.f, 0.f, 0.f, 0.f}; }
             colsum += a;
             *reinterpret_cast<f32x4*>(As + (lrow + RPP * i) * LDR + lc4) = a;
             *reinterpret_cast<f32x4*>(Bs + (lrow + RPP * i) * LDR + lc4) = b;
@@ -406,19 +419,40 @@ __global__ void transpose_k(const float* __restrict__ in, float* __restrict__ ou
         if (c0 + i < C && r0 + threadIdx.x < R) out[(int64_t)(c0 + i) * R + r0 + threadIdx.x] = tile[threadIdx.x][i];
 }
 
-template <int PRO, typename C>
+template <int PRO, typename C, bool RAGGED = false>
 int launch_nt(const NtArgs& a, int epi, hipStream_t st) {
-    const int64_t tiles = (a.M / C::BM) * (a.N / C::BN);
+    const int64_t tiles = ((a.M + C::BM - 1) / C::BM) * (a.N / C::BN);
     const int grid = (int)(tiles < C::SLOTS ? tiles : C::SLOTS);      // persistent over tiles
     switch (epi) {
-        case EPI_BIAS: gemm_nt_k<PRO, EPI_BIAS, C><<<grid, C::THREADS, 0, st>>>(a); break;
-        case EPI_BIAS_DROP_RES: gemm_nt_k<PRO, EPI_BIAS_DROP_RES, C><<<grid, C::THREADS, 0, st>>>(a); break;
-        case EPI_BIAS_GELU_DROP: gemm_nt_k<PRO, EPI_BIAS_GELU_DROP, C><<<grid, C::THREADS, 0, st>>>(a); break;
-        case EPI_GELU_BWD: gemm_nt_k<PRO, EPI_GELU_BWD, C><<<grid, C::THREADS, 0, st>>>(a); break;
-        case EPI_NONE: gemm_nt_k<PRO, EPI_NONE, C><<<grid, C::THREADS, 0, st>>>(a); break;
+        case EPI_BIAS: gemm_nt_k<PRO, EPI_BIAS, C, RAGGED><<<grid, C::THREADS, 0, st>>>(a); break;
+        case EPI_BIAS_DROP_RES: gemm_nt_k<PRO, EPI_BIAS_DROP_RES, C, RAGGED><<<grid, C::THREADS, 0, st>>>(a); break;
+        case EPI_BIAS_GELU_DROP: gemm_nt_k<PRO, EPI_BIAS_GELU_DROP, C, RAGGED><<<grid, C::THREADS, 0, st>>>(a); break;
+        case EPI_GELU_BWD: gemm_nt_k<PRO, EPI_GELU_BWD, C, RAGGED><<<grid, C::THREADS, 0, st>>>(a); break;
+        case EPI_NONE: gemm_nt_k<PRO, EPI_NONE, C, RAGGED><<<grid, C::THREADS, 0, st>>>(a); break;
         default: return HWGAT_EINVAL;
     }
     HWGAT_LAUNCH_CHECK();
+}
+
+// the same launch restricted to rows [r0, r0 + rows) of every M-indexed operand
+NtArgs nt_rows(NtArgs a, int64_t r0, int64_t rows) {
+    a.A += r0 * a.K;
+    a.C += r0 * a.N;
+    if (a.C2) a.C2 += r0 * a.N;
+    if (a.res) a.res += r0 * a.N;
+    if (a.aux) a.aux += r0 * a.N;
+    if (a.mean) { a.mean += r0; a.rstd += r0; }
+    a.M = rows;
+    a.row0 = r0;
+    return a;
+}
+TnArgs tn_rows(TnArgs a, int64_t r0, int64_t rows) {
+    a.A += r0 * a.N;
+    a.B += r0 * a.K;
+    if (a.mean) { a.mean += r0; a.rstd += r0; }
+    a.M = rows;
+    a.row0 = r0;
+    return a;
 }
 
 // tile choice; HWGAT_GEMM_TILE=small|big overrides (A/B measurements only)
@@ -430,7 +464,7 @@ int tile_override() {
     return v;
 }
 
-template <int PRO, bool BLN, typename C, bool MF16 = false>
+template <int PRO, bool BLN, typename C, bool MF16 = false, bool RAGGED = false>
 int launch_tn(TnArgs a, hipStream_t st) {
     constexpr int TM = C::BK;
     const int n_tiles = (a.N / C::BM) * (a.K / C::BM);
@@ -450,7 +484,7 @@ int launch_tn(TnArgs a, hipStream_t st) {
     a.n_split = (int)((a.M + rows - 1) / rows);
     a.rows_per_split = rows;
     const int grid = ((a.n_split + 7) / 8) * 8 * n_tiles;
-    gemm_tn_k<PRO, BLN, C, MF16><<<grid, C::THREADS, 0, st>>>(a);
+    gemm_tn_k<PRO, BLN, C, MF16, RAGGED><<<grid, C::THREADS, 0, st>>>(a);
     HWGAT_LAUNCH_CHECK();
 }
 
@@ -462,14 +496,31 @@ extern "C" int hwgat_linear_nt_f32(const float* A, const float* W, const float* 
                                    int epi, const float* res, float* C2, const float* aux, uint32_t epi_seed,
                                    float epi_p, void* stream) {
     if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) return HWGAT_EINVAL;
-    if (M % 128 || N % 128 || K % 32 || (M / 128) * (int64_t)(N / 128) > 0x7fffffff) return HWGAT_ESHAPE;
+    if (N % 128 || K % 32 || ((M + 127) / 128) * (int64_t)(N / 128) > 0x7fffffff) return HWGAT_ESHAPE;   // any M
     if (pro == PRO_LN && (!mean || !rstd || !gamma || !beta)) return HWGAT_EINVAL;
     if (epi == EPI_BIAS_DROP_RES && !res) return HWGAT_EINVAL;
     if (epi == EPI_BIAS_GELU_DROP && !C2) return HWGAT_EINVAL;
     if (epi == EPI_GELU_BWD && !aux) return HWGAT_EINVAL;
     if (pro_p < 0.f || pro_p >= 1.f || epi_p < 0.f || epi_p >= 1.f) return HWGAT_EINVAL;
-    NtArgs a{A, W, bias, C, C2, res, aux, mean, rstd, gamma, beta, M, N, K, pro_seed, epi_seed, pro_p, epi_p};
+    NtArgs a{A, W, bias, C, C2, res, aux, mean, rstd, gamma, beta, M, N, K, pro_seed, epi_seed, pro_p, epi_p, 0};
     hipStream_t st = (hipStream_t)stream;
+    // a token count that is not a multiple of the 128-row tile: bulk launch over the aligned rows with the
+    // unmodified kernels, then one small RAGGED launch for the last M % 128 rows
+    const int64_t m_bulk = M / 128 * 128;
+    if (m_bulk != M) {
+        if (m_bulk) {
+            const int rc = hwgat_linear_nt_f32(A, W, bias, C, m_bulk, N, K, pro, mean, rstd, gamma, beta, pro_seed, pro_p,
+                                               epi, res, C2, aux, epi_seed, epi_p, stream);
+            if (rc) return rc;
+        }
+        const NtArgs t = nt_rows(a, m_bulk, M - m_bulk);
+        switch (pro) {
+            case PRO_NONE: return launch_nt<PRO_NONE, NtSmall, true>(t, epi, st);
+            case PRO_LN: return launch_nt<PRO_LN, NtSmall, true>(t, epi, st);
+            case PRO_DROP: return launch_nt<PRO_DROP, NtSmall, true>(t, epi, st);
+            default: return HWGAT_EINVAL;
+        }
+    }
     // Tile choice, measured on MI355X (profiles/r01f_gemm_tile_ab.txt):
     //  - the 8-wave 256x256 tile loses to two independent 128x128 blocks per CU (110 vs 129 TF at
     //    K=512): kept only behind HWGAT_GEMM_TILE=big for A/B runs;
@@ -496,10 +547,20 @@ extern "C" int hwgat_linear_tn_f32(const float* A, const float* B, float* dW, fl
                                    const float* rstd, const float* gamma, const float* beta, void* stream) {
     if (!A || !B || !dW || M <= 0 || N <= 0 || K <= 0) return HWGAT_EINVAL;
     if (mean && (!rstd || !gamma || !beta)) return HWGAT_EINVAL;
-    if (M % 32 || N % 128 || K % 128) return HWGAT_ESHAPE;
+    if (N % 128 || K % 128) return HWGAT_ESHAPE;                 // any M
     if (pro_p < 0.f || pro_p >= 1.f) return HWGAT_EINVAL;
-    TnArgs a{A, B, dW, db, mean, rstd, gamma, beta, M, N, K, 0, 0, pro_seed, pro_p};
+    TnArgs a{A, B, dW, db, mean, rstd, gamma, beta, M, N, K, 0, 0, pro_seed, pro_p, 0};
     hipStream_t st = (hipStream_t)stream;
+    const int64_t m_bulk = M / 32 * 32;                         // rows per LDS stage; the tail gets a RAGGED launch
+    if (m_bulk != M) {
+        if (m_bulk) {
+            const int rc = hwgat_linear_tn_f32(A, B, dW, db, m_bulk, N, K, pro_seed, pro_p, mean, rstd, gamma, beta, stream);
+            if (rc) return rc;
+        }
+        const TnArgs t = tn_rows(a, m_bulk, M - m_bulk);
+        if (pro_p > 0.f) return mean ? launch_tn<PRO_DROP, true, TnSmall, false, true>(t, st) : launch_tn<PRO_DROP, false, TnSmall, false, true>(t, st);
+        return mean ? launch_tn<PRO_NONE, true, TnSmall, false, true>(t, st) : launch_tn<PRO_NONE, false, TnSmall, false, true>(t, st);
+    }
     // 256-aligned multi-tile outputs: the one-wave-per-SIMD 256x256 kernel with pinned MFMA/memory
     // interleave (gemm_f32_tn256.hip; +2..8 % over the variants below, e.g. 131 vs 121-126 TF on
     // 1536x512).  Single 256x256 outputs and everything else: 128x128 blocks, two per CU.

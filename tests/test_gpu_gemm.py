@@ -96,6 +96,60 @@ def test_tn_weight_and_bias_grad(M, N, K, p):
     assert rel_err(dW.cpu(), 2 * ref) < TOL
 
 
+@pytest.mark.parametrize("M", [1, 29, 127, 129, 928, 864, 128 * 5 + 17])
+def test_ragged_token_counts(M):
+    """M % 128 != 0 (HGATE: M = B*F*29): the last row block clamps its loads and guards its stores.
+    Outputs are allocated with canary rows behind them: nothing may be written past row M-1."""
+    N, K, p = 256, 128, 0.1
+    A, W, b = _data(M, N, K, 7 + M)
+    g = torch.Generator().manual_seed(M)
+    res = torch.randn(M, N, generator=g)
+    gamma, beta = torch.randn(K, generator=g), torch.randn(K, generator=g)
+    Ad, Wd, bd = A.to(DEV), W.to(DEV), b.to(DEV)
+    mean, rstd = HF.ln_stats(Ad, gamma.to(DEV), beta.to(DEV))
+    lin = A.double() @ W.double().t() + b.double()
+    lnlin = torch.nn.functional.layer_norm(A.double(), (K,), gamma.double(), beta.double()) @ W.double().t() + b.double()
+    mask = HF.dropout_mask((M, N), 1234, p, DEV).cpu().double()
+
+    def canary():
+        buf = torch.full((M + 160, N), 777.0, device=DEV)
+        return buf, buf[:M]
+
+    buf, out = canary()
+    HF.linear_nt(Ad, Wd, bd, epi=HF.EPI_BIAS, out=out)
+    assert rel_err(out.cpu(), lin) < TOL and bool((buf[M:] == 777.0).all())
+    buf, out = canary()
+    HF.linear_nt(Ad, Wd, bd, pro=HF.PRO_LN, ln=(mean, rstd, gamma.to(DEV), beta.to(DEV)), out=out)
+    assert rel_err(out.cpu(), lnlin) < TOL and bool((buf[M:] == 777.0).all())
+    buf, out = canary()
+    HF.linear_nt(Ad, Wd, bd, epi=HF.EPI_BIAS_DROP_RES, res=res.to(DEV), epi_seed=1234, epi_p=p, out=out)
+    assert rel_err(out.cpu(), res.double() + lin * mask) < TOL and bool((buf[M:] == 777.0).all())
+    u, h1 = HF.linear_nt(Ad, Wd, bd, epi=HF.EPI_BIAS_GELU_DROP, epi_seed=1234, epi_p=p)
+    assert rel_err(h1.cpu(), lin) < TOL and rel_err(u.cpu(), torch.nn.functional.gelu(lin) * mask) < TOL
+    maskA = HF.dropout_mask((M, K), 77, p, DEV).cpu().double()
+    got = HF.linear_nt(Ad, Wd, None, pro=HF.PRO_DROP, pro_seed=77, pro_p=p, epi=HF.EPI_NONE)
+    assert rel_err(got.cpu(), (A.double() * maskA) @ W.double().t()) < TOL
+    # weight gradients: small-tile kernel (N*K = 256*128), the 256x256 kernel (512x256), LayerNorm on B
+    dY = torch.randn(M, N, generator=g)
+    for NN, KK in ((N, K), (512, 256)):
+        dYn = torch.randn(M, NN, generator=g)
+        Xn = torch.randn(M, KK, generator=g)
+        dW, db = torch.zeros(NN, KK, device=DEV), torch.zeros(NN, device=DEV)
+        HF.linear_tn(dYn.to(DEV), Xn.to(DEV), dW, db)
+        assert rel_err(dW.cpu(), dYn.double().t() @ Xn.double()) < TOL
+        assert rel_err(db.cpu(), dYn.double().sum(0)) < TOL
+        mk = HF.dropout_mask((M, NN), 5, p, DEV).cpu().double()
+        dW.zero_()
+        db.zero_()
+        HF.linear_tn(dYn.to(DEV), Xn.to(DEV), dW, db, pro_seed=5, pro_p=p)
+        assert rel_err(dW.cpu(), (dYn.double() * mk).t() @ Xn.double()) < TOL
+        assert rel_err(db.cpu(), (dYn.double() * mk).sum(0)) < TOL
+    dW = torch.zeros(N, K, device=DEV)
+    HF.linear_tn(dY.to(DEV), Ad, dW, None, ln=(mean, rstd, gamma.to(DEV), beta.to(DEV)))
+    ref = dY.double().t() @ torch.nn.functional.layer_norm(A.double(), (K,), gamma.double(), beta.double())
+    assert rel_err(dW.cpu(), ref) < TOL
+
+
 def test_transpose():
     W = torch.randn(384, 128)
     assert torch.equal(HF.transpose(W.to(DEV)).cpu(), W.t().contiguous())

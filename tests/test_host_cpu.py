@@ -86,8 +86,10 @@ def test_c_abi_rejects_bad_arguments_without_launching():
     assert L.hwgat_win_attn_fwd(p, p, p, None, 1, 4, 1, 2, 48, 0, 0, None) == -2             # head_dim 48
     assert L.hwgat_win_attn_bwd(p, p, p, p, None, 1, 4, 1, 2, 64, 0, 7, None) == -3          # HWGAT_EDTYPE
     assert L.hwgat_ln_fwd(p, p, p, p, p, p, 8, 100, 0, None) == -2                           # width 100
-    assert L.hwgat_linear_nt_f32(p, p, None, p, 100, 128, 128, 0, None, None, None, None, 0, 0.0, 0,
-                                 None, None, None, 0, 0.0, None) == -2                        # M % 128
+    assert L.hwgat_linear_nt_f32(p, p, None, p, 128, 100, 128, 0, None, None, None, None, 0, 0.0, 0,
+                                 None, None, None, 0, 0.0, None) == -2                        # N % 128 (any M is fine)
+    assert L.hwgat_linear_nt_f32(p, p, None, p, 0, 128, 128, 0, None, None, None, None, 0, 0.0, 0,
+                                 None, None, None, 0, 0.0, None) == -1                        # M <= 0
     assert L.hwgat_linear_nt_f32(p, p, None, p, 128, 128, 128, 1, None, None, None, None, 0, 0.0, 0,
                                  None, None, None, 0, 0.0, None) == -1                        # LN prologue w/o stats
     assert L.hwgat_linear_nt_f32(p, p, None, p, 128, 128, 128, 0, None, None, None, None, 0, 0.0, 1,
