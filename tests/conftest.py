@@ -17,3 +17,17 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def pytest_sessionstart(session):
+    """make sure libhwgat_hip.so matches the sources: build.py is a no-op when the digest stamp is
+    current (the normal case: the .so travels with the tree) and recompiles with hipcc otherwise.  A
+    failure here is left to surface in the tests themselves (the library loader fails loudly)."""
+    import importlib.util
+    try:
+        spec = importlib.util.spec_from_file_location("hwgat_build", os.path.join(ROOT, "sl-hwgat_amd", "build.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        mod.build()
+    except Exception as exc:                                   # noqa: BLE001
+        sys.stderr.write(f"[conftest] could not (re)build libhwgat_hip.so: {exc}\n")
