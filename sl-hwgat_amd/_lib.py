@@ -34,6 +34,8 @@ _SIGS = {
     "hwgat_band_attn_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "hwgat_band_attn_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "hwgat_debug_mfma16x16x4": [_P, _P, _P, _P],
+    "hwgat_split3_bf16": [_P, _P, _L, _P],
+    "hwgat_linear_nt_f32x9": [_P, _P, _P, _L, _I, _I, _P],
     "hwgat_lnpool_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "hwgat_lnpool_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "hwgat_merge": [_P, _P, _I, _I, _I, _I, _I, _I, _P],

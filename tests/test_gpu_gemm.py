@@ -150,6 +150,28 @@ def test_ragged_token_counts(M):
     assert rel_err(dW.cpu(), ref) < TOL
 
 
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (640, 384, 128), (1152, 512, 1536)])
+def test_x9_split_is_exact_and_product_has_fp32_accuracy(M, N, K):
+    """EXPERIMENT kernels (opt-in): the three bf16 pieces add up to the fp32 value exactly, and the nine-product
+    GEMM is as close to the fp64 result as the fp32-MFMA kernel is"""
+    A, W, _ = _data(M, N, K, 11 + M)
+    A = A * torch.exp(3 * torch.randn(M, 1, generator=torch.Generator().manual_seed(2)))     # wide dynamic range
+    Wd = W.to(DEV)
+    W3 = HF.split3(Wd)
+    assert torch.equal(W3.float().double().sum(0).float().cpu(), W)            # exact 3-way split
+    assert torch.equal((W3[0].float() + (W3[1].float() + W3[2].float())).cpu(), W)
+    ref = A.double() @ W.double().t()
+    got9 = HF.linear_nt_x9(A.to(DEV), W3)
+    got32 = HF.linear_nt(A.to(DEV), Wd, None, epi=HF.EPI_NONE)
+    e9, e32 = rel_err(got9.cpu(), ref), rel_err(got32.cpu(), ref)
+    assert e9 < TOL and e9 < 2 * e32 + 1e-8, (e9, e32)
+    # elementwise: worst absolute error relative to the row/column magnitude, same bound for both
+    scale = (A.double().abs() @ W.double().abs().t()).clamp_min(1e-30)
+    w9 = ((got9.cpu().double() - ref).abs() / scale).max().item()
+    w32 = ((got32.cpu().double() - ref).abs() / scale).max().item()
+    assert w9 < 4e-7 and w9 < 2 * w32 + 1e-8, (w9, w32)
+
+
 def test_transpose():
     W = torch.randn(384, 128)
     assert torch.equal(HF.transpose(W.to(DEV)).cpu(), W.t().contiguous())
