@@ -14,6 +14,7 @@
 //   C[M,N] = A[M,K] . W[N,K]^T,  A fp32 (split on the fly while staging to LDS),
 //   W given as three bf16 planes [3][N][K] (hwgat_split3_bf16, once per weight).
 //   128x128 tile, 4 waves x (64x64), K slabs of 16, three operand planes per side, double-buffered in LDS.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -140,6 +141,111 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_x9_k(const float* __restrict__
                 C[(m0 + wm * 64 + i * 32 + crow(r, hh)) * N + n0 + wn * 64 + j * 32 + lq] = acc[i][j][r];
 }
 
+// 256x256 tile, 4 waves x (128x128 = 4x4 MFMA tiles, 256 accumulator registers), ONE wave per SIMD, K slabs of 16
+// double-buffered (3 planes x 512 rows x 48 B x 2 = 144 KB): 52 flop per staged byte instead of 26 -- the 128x128
+// form is bound by L2->LDS operand traffic, not by the MFMAs.
+constexpr int BM3 = 256, BN3 = 256, PLANE3 = (BM3 + BN3) * LDT2, BUF3 = 3 * PLANE3;
+
+template <int MODE>   // 0 = the kernel; 1 = skip loads + split + LDS writes after the first slab; 2 = skip the MFMAs (timing probes)
+__global__ __launch_bounds__(256, 1) void gemm_nt_x9_256_k(const float* __restrict__ A, const uint16_t* __restrict__ Wp,
+                                                           float* __restrict__ C, int64_t M, int N, int K) {
+    __shared__ __attribute__((aligned(16))) uint16_t sm[2 * BUF3];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane & 31, hh = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = N / BN3;
+    const int64_t m0 = (int64_t)(blockIdx.x / tiles_n) * BM3;
+    const int n0 = (blockIdx.x % tiles_n) * BN3;
+    const int n_slab = K / BK2;
+    const int64_t plane_w = (int64_t)N * K;
+
+    // staging roles: A: rows arow + 64 i (i < 4), floats ac4..ac4+3;  W: 16-byte chunks idx = tid + 256 q of [3][256][2]
+    const int arow = tid >> 2, ac4 = (tid & 3) * 4;
+    f32x4 ra[4];
+    u32x4 rw[6];
+    auto issue = [&](int s) {
+        const int k0 = s * BK2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const f32x4*>(A + (m0 + arow + 64 * i) * K + k0 + ac4);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const int idx = tid + 256 * q, pl = idx >> 9, rem = idx & 511, row = rem >> 1, ch = rem & 1;
+            rw[q] = *reinterpret_cast<const u32x4*>(Wp + pl * plane_w + (int64_t)(n0 + row) * K + k0 + ch * 8);
+        }
+    };
+    auto commit = [&](int buf) {
+        uint16_t* b = sm + buf * BUF3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint32_t lo[3], hi[3];
+            split2(ra[i].x, ra[i].y, lo);
+            split2(ra[i].z, ra[i].w, hi);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                u32x2 v = {lo[pl], hi[pl]};
+                *reinterpret_cast<u32x2*>(b + pl * PLANE3 + (arow + 64 * i) * LDT2 + ac4) = v;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const int idx = tid + 256 * q, pl = idx >> 9, rem = idx & 511, row = rem >> 1, ch = rem & 1;
+            *reinterpret_cast<u32x4*>(b + pl * PLANE3 + (BM3 + row) * LDT2 + ch * 8) = rw[q];
+        }
+    };
+
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    issue(0);
+    commit(0);
+    __syncthreads();
+    int buf = 0;
+    for (int s = 0; s < n_slab; ++s) {
+        const bool have_next = MODE == 1 ? false : s + 1 < n_slab;
+        if (have_next) issue(s + 1);
+        const uint16_t* ap = sm + buf * BUF3 + (wm * 128 + lq) * LDT2 + 8 * hh;
+        const uint16_t* wp = sm + buf * BUF3 + (BM3 + wn * 128 + lq) * LDT2 + 8 * hh;
+        // one plane pair at a time, smallest terms first; the fragments of a pair are 8 reads for 16 MFMAs
+        bf16x8 af[3][4], bfr[3][4];
+#pragma unroll
+        for (int pl = 2; pl >= 0; --pl)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[pl][i] = *reinterpret_cast<const bf16x8*>(ap + pl * PLANE3 + i * 32 * LDT2);
+                bfr[pl][i] = *reinterpret_cast<const bf16x8*>(wp + pl * PLANE3 + i * 32 * LDT2);
+            }
+#pragma unroll
+        for (int sum = 4; sum >= 0; --sum)
+#pragma unroll
+            for (int pa = 0; pa < 3; ++pa) {
+                const int pb = sum - pa;
+                if (pb < 0 || pb > 2) continue;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if constexpr (MODE == 2) { if (pa + pb + i + j == 0) acc[i][j][0] += (float)af[pa][i][0] * (float)bfr[pb][j][0]; }
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pa][i], bfr[pb][j], acc[i][j], 0, 0, 0);
+                    }
+            }
+        if (have_next) commit(buf ^ 1);
+        __syncthreads();
+        if (MODE != 1) buf ^= 1;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                C[(m0 + wm * 128 + i * 32 + crow(r, hh)) * N + n0 + wn * 128 + j * 32 + lq] = acc[i][j][r];
+}
+
 __global__ void split3_k(const float* __restrict__ in, uint16_t* __restrict__ out, int64_t n) {
     for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2; i < n; i += (int64_t)gridDim.x * 512) {
         uint32_t p[3];
@@ -162,6 +268,15 @@ extern "C" int hwgat_linear_nt_f32x9(const float* A, const uint16_t* W3, float* 
                                      void* stream) {
     if (!A || !W3 || !C || M <= 0 || N <= 0 || K <= 0) return HWGAT_EINVAL;
     if (M % BM || N % BN || K % 32 || (M / BM) * (int64_t)(N / BN) > 0x7fffffff) return HWGAT_ESHAPE;
-    gemm_nt_x9_k<<<(int)((M / BM) * (N / BN)), 256, 0, (hipStream_t)stream>>>(A, W3, C, M, N, K);
+    static const bool small_only = getenv("HWGAT_X9_TILE") && getenv("HWGAT_X9_TILE")[0] == 's';
+    static const int mode = getenv("HWGAT_X9_MODE") ? atoi(getenv("HWGAT_X9_MODE")) : 0;
+    if (M % BM3 == 0 && N % BN3 == 0 && !small_only) {
+        const int grid = (int)((M / BM3) * (N / BN3));
+        if (mode == 1) gemm_nt_x9_256_k<1><<<grid, 256, 0, (hipStream_t)stream>>>(A, W3, C, M, N, K);
+        else if (mode == 2) gemm_nt_x9_256_k<2><<<grid, 256, 0, (hipStream_t)stream>>>(A, W3, C, M, N, K);
+        else gemm_nt_x9_256_k<0><<<grid, 256, 0, (hipStream_t)stream>>>(A, W3, C, M, N, K);
+    }
+    else
+        gemm_nt_x9_k<<<(int)((M / BM) * (N / BN)), 256, 0, (hipStream_t)stream>>>(A, W3, C, M, N, K);
     HWGAT_LAUNCH_CHECK();
 }

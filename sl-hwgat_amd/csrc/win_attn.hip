@@ -375,6 +375,31 @@ __global__ __launch_bounds__(256) void mfma_peak16_k(float* out, int iters, floa
     if (s == 12345.678f) out[threadIdx.x] = s;
 }
 
+// the same with v_mfma_f32_32x32x16_bf16: NACC independent 32x32 tiles, 32768 flop per MFMA
+template <int NACC>
+__global__ __launch_bounds__(256) void mfma_peak_bf16_k(float* out, int iters, float seed) {
+    f32x16 acc[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[a][i] = 0.f;
+    bf16x8 x, y;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { x[i] = (bf16_t)(seed + threadIdx.x * 1e-3f + i); y[i] = (bf16_t)(seed * 0.5f + i * 0.25f); }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int a = 0; a < NACC; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, acc[a], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += acc[a][i];
+    if (s == 12345.678f) out[threadIdx.x] = s;
+}
+
 bool geom_ok(int B, int F, int nW, int nH, int hd) {
     return B > 0 && F > 0 && (F % 2) == 0 && nW > 0 && nH > 0 && (hd == 32 || hd == 64 || hd == 128);
 }
@@ -415,6 +440,8 @@ extern "C" int hwgat_debug_mfma_peak(float* out, int blocks, int iters, int n_ac
     if (n_acc == 4) mfma_peak_k<4><<<blocks, 256, 0, st>>>(out, iters, 1.0f);
     else if (n_acc == 16) mfma_peak_k<16><<<blocks, 256, 0, st>>>(out, iters, 1.0f);
     else if (n_acc == -4) mfma_peak16_k<4><<<blocks, 256, 0, st>>>(out, iters, 1.0f);      // 16x16x4 form
+    else if (n_acc == 100 + 4) mfma_peak_bf16_k<4><<<blocks, 256, 0, st>>>(out, iters, 1.0f);   // bf16 32x32x16, 4 x NACC x 32768 flop per iteration per wave
+    else if (n_acc == 100 + 16) mfma_peak_bf16_k<16><<<blocks, 256, 0, st>>>(out, iters, 1.0f);
     else return HWGAT_ESHAPE;
     HWGAT_LAUNCH_CHECK();
 }

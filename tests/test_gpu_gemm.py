@@ -150,7 +150,7 @@ def test_ragged_token_counts(M):
     assert rel_err(dW.cpu(), ref) < TOL
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (640, 384, 128), (1152, 512, 1536)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (640, 384, 128), (1152, 512, 1536), (1280, 512, 1024), (256, 256, 32)])
 def test_x9_split_is_exact_and_product_has_fp32_accuracy(M, N, K):
     """EXPERIMENT kernels (opt-in): the three bf16 pieces add up to the fp32 value exactly, and the nine-product
     GEMM is as close to the fp64 result as the fp32-MFMA kernel is"""
