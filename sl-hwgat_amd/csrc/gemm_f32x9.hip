@@ -15,6 +15,7 @@
 //   W given as three bf16 planes [3][N][K] (hwgat_split3_bf16, once per weight).
 //   128x128 tile, 4 waves x (64x64), K slabs of 16, three operand planes per side, double-buffered in LDS.
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -146,7 +147,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_x9_k(const float* __restrict__
 // form is bound by L2->LDS operand traffic, not by the MFMAs.
 constexpr int BM3 = 256, BN3 = 256, PLANE3 = (BM3 + BN3) * LDT2, BUF3 = 3 * PLANE3;
 
-template <int MODE>   // 0 = the kernel; 1 = skip loads + split + LDS writes after the first slab; 2 = skip the MFMAs (timing probes)
+// LLVM SchedGroupMask bits
+constexpr int SG_VALU = 0x002, SG_MFMA = 0x008, SG_VMEM_RD = 0x020, SG_DS_RD = 0x100, SG_DS_WR = 0x200;
+
+// Slab s+2 is requested at the top of slab s into one of TWO register sets and written to LDS during slab s+1
+// (a load has a whole slab of 144 MFMAs to land); its staging is cut into 12 small steps (one half-row split,
+// ~11 vector instructions, or two LDS writes), one behind every 4th of the last 48 MFMAs, fenced so that it
+// stays there: an MFMA holds the vector issue port for 8 of its 32 cycles, the rest of the gap is free.
+// PIN = 0 keeps the compiler's own order (staging after the MFMAs) for A/B runs.
+template <int PIN>
 __global__ __launch_bounds__(256, 1) void gemm_nt_x9_256_k(const float* __restrict__ A, const uint16_t* __restrict__ Wp,
                                                            float* __restrict__ C, int64_t M, int N, int K) {
     __shared__ __attribute__((aligned(16))) uint16_t sm[2 * BUF3];
@@ -156,14 +165,14 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_x9_256_k(const float* __restri
     const int tiles_n = N / BN3;
     const int64_t m0 = (int64_t)(blockIdx.x / tiles_n) * BM3;
     const int n0 = (blockIdx.x % tiles_n) * BN3;
-    const int n_slab = K / BK2;
+    const int n_slab = K / BK2;                                  // even (K % 32 == 0)
     const int64_t plane_w = (int64_t)N * K;
 
     // staging roles: A: rows arow + 64 i (i < 4), floats ac4..ac4+3;  W: 16-byte chunks idx = tid + 256 q of [3][256][2]
     const int arow = tid >> 2, ac4 = (tid & 3) * 4;
-    f32x4 ra[4];
-    u32x4 rw[6];
-    auto issue = [&](int s) {
+    f32x4 ra0[4], ra1[4];
+    u32x4 rw0[6], rw1[6];
+    auto issue = [&](int s, f32x4 (&ra)[4], u32x4 (&rw)[6]) {
         const int k0 = s * BK2;
 #pragma unroll
         for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const f32x4*>(A + (m0 + arow + 64 * i) * K + k0 + ac4);
@@ -173,23 +182,28 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_x9_256_k(const float* __restri
             rw[q] = *reinterpret_cast<const u32x4*>(Wp + pl * plane_w + (int64_t)(n0 + row) * K + k0 + ch * 8);
         }
     };
-    auto commit = [&](int buf) {
-        uint16_t* b = sm + buf * BUF3;
+    // step k of 12 of writing one slab (registers ra, rw) into LDS buffer nb
+    uint32_t plo[3], phi[3];
+    auto commit_step = [&](int k, uint16_t* nb, const f32x4 (&ra)[4], const u32x4 (&rw)[6]) {
+        if (k < 8) {
+            const int i = k >> 1;
+            if ((k & 1) == 0) {
+                split2(ra[i].x, ra[i].y, plo);
+            } else {
+                split2(ra[i].z, ra[i].w, phi);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            uint32_t lo[3], hi[3];
-            split2(ra[i].x, ra[i].y, lo);
-            split2(ra[i].z, ra[i].w, hi);
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
-                u32x2 v = {lo[pl], hi[pl]};
-                *reinterpret_cast<u32x2*>(b + pl * PLANE3 + (arow + 64 * i) * LDT2 + ac4) = v;
+                for (int pl = 0; pl < 3; ++pl) {
+                    u32x2 v = {plo[pl], phi[pl]};
+                    *reinterpret_cast<u32x2*>(nb + pl * PLANE3 + (arow + 64 * i) * LDT2 + ac4) = v;
+                }
             }
-        }
+        } else {
+            const int q0 = (k - 8) * 2;
 #pragma unroll
-        for (int q = 0; q < 6; ++q) {
-            const int idx = tid + 256 * q, pl = idx >> 9, rem = idx & 511, row = rem >> 1, ch = rem & 1;
-            *reinterpret_cast<u32x4*>(b + pl * PLANE3 + (BM3 + row) * LDT2 + ch * 8) = rw[q];
+            for (int q = q0; q < q0 + 2 && q < 6; ++q) {
+                const int idx = tid + 256 * q, pl = idx >> 9, rem = idx & 511, row = rem >> 1, ch = rem & 1;
+                *reinterpret_cast<u32x4*>(nb + pl * PLANE3 + (BM3 + row) * LDT2 + ch * 8) = rw[q];
+            }
         }
     };
 
@@ -201,41 +215,61 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_x9_256_k(const float* __restri
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    issue(0);
-    commit(0);
-    __syncthreads();
-    int buf = 0;
-    for (int s = 0; s < n_slab; ++s) {
-        const bool have_next = MODE == 1 ? false : s + 1 < n_slab;
-        if (have_next) issue(s + 1);
+    // slab s computes from LDS buffer s & 1; `cur` = register set that holds slab s+1 (staged during this slab),
+    // `nxt` = the set slab s+2 is loaded into (it held slab s, already staged).  After the last slab the staging
+    // writes stale registers into the buffer nobody reads again.
+    auto slab = [&](int s, f32x4 (&cur_a)[4], u32x4 (&cur_w)[6], f32x4 (&nxt_a)[4], u32x4 (&nxt_w)[6]) {
+        const int buf = s & 1;
+        if (s + 2 < n_slab) issue(s + 2, nxt_a, nxt_w);
+        __builtin_amdgcn_sched_barrier(0);                                          // the loads stay at the top of the slab
         const uint16_t* ap = sm + buf * BUF3 + (wm * 128 + lq) * LDT2 + 8 * hh;
         const uint16_t* wp = sm + buf * BUF3 + (BM3 + wn * 128 + lq) * LDT2 + 8 * hh;
-        // one plane pair at a time, smallest terms first; the fragments of a pair are 8 reads for 16 MFMAs
-        bf16x8 af[3][4], bfr[3][4];
+        uint16_t* nb = sm + (buf ^ 1) * BUF3;
+        // 144 MFMAs in three passes over the A planes (W fragments of all three planes resident: 48 registers)
+        bf16x8 bfr[3][4], af[3][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[2][i] = *reinterpret_cast<const bf16x8*>(ap + 2 * PLANE3 + i * 32 * LDT2);
 #pragma unroll
         for (int pl = 2; pl >= 0; --pl)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                af[pl][i] = *reinterpret_cast<const bf16x8*>(ap + pl * PLANE3 + i * 32 * LDT2);
-                bfr[pl][i] = *reinterpret_cast<const bf16x8*>(wp + pl * PLANE3 + i * 32 * LDT2);
-            }
+            for (int i = 0; i < 4; ++i) bfr[pl][i] = *reinterpret_cast<const bf16x8*>(wp + pl * PLANE3 + i * 32 * LDT2);
 #pragma unroll
-        for (int sum = 4; sum >= 0; --sum)
+        for (int pl = 1; pl >= 0; --pl)
 #pragma unroll
-            for (int pa = 0; pa < 3; ++pa) {
-                const int pb = sum - pa;
-                if (pb < 0 || pb > 2) continue;
+            for (int i = 0; i < 4; ++i) af[pl][i] = *reinterpret_cast<const bf16x8*>(ap + pl * PLANE3 + i * 32 * LDT2);
+#pragma unroll
+        for (int pa = 2; pa >= 0; --pa)
+#pragma unroll
+            for (int pb = 2; pb >= 0; --pb)
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        if constexpr (MODE == 2) { if (pa + pb + i + j == 0) acc[i][j][0] += (float)af[pa][i][0] * (float)bfr[pb][j][0]; }
-                        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pa][i], bfr[pb][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[pa][i], bfr[pb][j], acc[i][j], 0, 0, 0);
+                        if constexpr (PIN == 1) {
+                            const int idx = ((2 - pa) * 3 + (2 - pb)) * 16 + i * 4 + j;
+                            if (idx >= 96 && (idx & 3) == 3) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                commit_step((idx - 96) >> 2, nb, cur_a, cur_w);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
                     }
-            }
-        if (have_next) commit(buf ^ 1);
+        if constexpr (PIN == 0) {
+#pragma unroll
+            for (int k = 0; k < 12; ++k) commit_step(k, nb, cur_a, cur_w);
+        }
         __syncthreads();
-        if (MODE != 1) buf ^= 1;
+    };
+
+    issue(0, ra0, rw0);
+#pragma unroll
+    for (int k = 0; k < 12; ++k) commit_step(k, sm, ra0, rw0);
+    issue(1, ra1, rw1);
+    __syncthreads();
+    for (int s = 0; s < n_slab; s += 2) {
+        slab(s, ra1, rw1, ra0, rw0);             // stages slab s+1 (set 1), loads slab s+2 into set 0
+        slab(s + 1, ra0, rw0, ra1, rw1);         // stages slab s+2 (set 0), loads slab s+3 into set 1
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -269,12 +303,11 @@ extern "C" int hwgat_linear_nt_f32x9(const float* A, const uint16_t* W3, float* 
     if (!A || !W3 || !C || M <= 0 || N <= 0 || K <= 0) return HWGAT_EINVAL;
     if (M % BM || N % BN || K % 32 || (M / BM) * (int64_t)(N / BN) > 0x7fffffff) return HWGAT_ESHAPE;
     static const bool small_only = getenv("HWGAT_X9_TILE") && getenv("HWGAT_X9_TILE")[0] == 's';
-    static const int mode = getenv("HWGAT_X9_MODE") ? atoi(getenv("HWGAT_X9_MODE")) : 0;
+    static const int pin = getenv("HWGAT_X9_PIN") ? atoi(getenv("HWGAT_X9_PIN")) : 1;   // 0: compiler order (A/B)
     if (M % BM3 == 0 && N % BN3 == 0 && !small_only) {
         const int grid = (int)((M / BM3) * (N / BN3));
-        if (mode == 1) gemm_nt_x9_256_k<1><<<grid, 256, 0, (hipStream_t)stream>>>(A, W3, C, M, N, K);
-        else if (mode == 2) gemm_nt_x9_256_k<2><<<grid, 256, 0, (hipStream_t)stream>>>(A, W3, C, M, N, K);
-        else gemm_nt_x9_256_k<0><<<grid, 256, 0, (hipStream_t)stream>>>(A, W3, C, M, N, K);
+        if (pin == 0) gemm_nt_x9_256_k<0><<<grid, 256, 0, (hipStream_t)stream>>>(A, W3, C, M, N, K);
+        else gemm_nt_x9_256_k<1><<<grid, 256, 0, (hipStream_t)stream>>>(A, W3, C, M, N, K);
     }
     else
         gemm_nt_x9_k<<<(int)((M / BM) * (N / BN)), 256, 0, (hipStream_t)stream>>>(A, W3, C, M, N, K);
