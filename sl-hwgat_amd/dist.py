@@ -98,3 +98,5 @@ def broadcast_parameters(module, src: int = 0, group=None):
         return
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src=src, group=group)
+    # every rank draws its own dropout masks (the models hash (seed, rank_salt, call, site, element))
+    module.rank_salt = dist.get_rank(group)

@@ -155,7 +155,10 @@ class Model(nn.Module):
 
     def _seeds(self, k):
         """three dropout-site seeds for block k of this forward call (host integers, no sync)"""
-        base = (torch.initial_seed() * 0x9E3779B1 + self._drop_calls * 0x85EBCA77) & 0xFFFFFFFF
+        # rank_salt: data-parallel ranks share torch's seed (identical initial weights) but must not share
+        # dropout masks (SURVEY 8e); dist.broadcast_parameters() sets it to the rank
+        base = (torch.initial_seed() * 0x9E3779B1 + self._drop_calls * 0x85EBCA77
+                + getattr(self, "rank_salt", 0) * 0x27D4EB2F) & 0xFFFFFFFF
         return [(base + (k * 4 + s) * 0xC2B2AE35) & 0xFFFFFFFF for s in range(3)]
 
     def _block(self, h, blk, n_heads, shifted, thr, k=0):

@@ -177,3 +177,17 @@ def test_sibling_mask_rows_on_cpu():
         HF.band_mask_rows(no_diag, T)
     with pytest.raises(ValueError):
         HF.band_mask_rows(band, T + 1)
+
+
+def test_dropout_seeds_differ_per_rank_and_per_call():
+    """data-parallel ranks share torch's seed but not dropout masks: rank_salt enters the site seeds"""
+    hp = hw.HWGATEParams({"src_len": 32, "num_class": 5}, 2, torch.device("cpu"), num_kps=32)
+    torch.manual_seed(1001)
+    m = hw.Model(*hp.get_model_params())
+    base = m._seeds(3)
+    assert len(set(base)) == 3 and m._seeds(3) == base and m._seeds(4) != base
+    m.rank_salt = 1
+    assert m._seeds(3) != base and len(set(m._seeds(3)) & set(base)) == 0
+    m.rank_salt = 0
+    m._drop_calls += 1
+    assert m._seeds(3) != base
