@@ -195,7 +195,7 @@ int hwgat_linear_tn_f32(const float* A, const float* B, float* dW, float* db, in
 /* ---- BASELINE config 3: the same two linears with bf16 activations / weights on
  * v_mfma_f32_32x32x16_bf16 (fp32 accumulate).  A, W, C, C2, res, aux are bf16; bias, LN
  * statistics/affine, dW, db stay fp32.  Semantics, prologue/epilogue codes and dropout masks are
- * identical to the fp32 entry points; K % 64 == 0 here. */
+ * identical to the fp32 entry points (any M >= 1: a ragged tail gets its own small launch); K % 64 == 0 here. */
 int hwgat_linear_nt_bf16(const void* A, const void* W, const float* bias, void* C, int64_t M, int N, int K,
                          int pro, const float* mean, const float* rstd, const float* gamma,
                          const float* beta, uint32_t pro_seed, float pro_p, int epi, const void* res,

@@ -43,6 +43,7 @@ struct NtArgsB {
     const float* mean; const float* rstd; const float* gamma; const float* beta;
     int64_t M; int N, K;
     uint32_t pro_seed, epi_seed; float pro_p, epi_p;
+    int64_t row0;          // RAGGED tail launches: global index of this launch's first row (dropout hash)
 };
 
 // 128x128 tile, 4 waves, K slabs of 64 (144-byte LDS rows), 72 KB -> 2 blocks / CU.
@@ -58,7 +59,9 @@ struct SlabIt {
     bool valid;
 };
 
-template <int PRO, int EPI, typename C>
+// RAGGED: launch over the last M % 128 rows of a token count that is not a multiple of the tile (see the fp32
+// family, gemm_f32.hip): clamped loads, guarded stores, dropout hashed with the global row index.
+template <int PRO, int EPI, typename C, bool RAGGED = false>
 __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt_bf16_k(NtArgsB p) {
     constexpr int BM = C::BM, BN = C::BN, BK = C::BK, LDT = C::LDT, PA = C::PA, PW = C::PW, RPP = C::RPP;
     constexpr int TMW = C::TMW, TNW = C::TNW;
@@ -67,13 +70,14 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt
     const int lq = lane & 31, hh = lane >> 5;
     const int wm = wave / C::WN, wn = wave % C::WN;
     const int tiles_n = p.N / BN;
-    const int n_tiles = (int)(p.M / BM) * tiles_n;
+    const int row_blocks = RAGGED ? (int)((p.M + BM - 1) / BM) : (int)(p.M / BM);
+    const int n_tiles = row_blocks * tiles_n;
+    const int64_t m_last = p.M - 1;
     const int n_slab = p.K / BK;
     const int lrow = tid / C::TPR, lc8 = (tid % C::TPR) * 8;   // rows lrow + RPP*i, bf16 columns lc8..lc8+7
     const uint32_t pro_th = drop_thresh(p.pro_p);
     const float pro_sc = 1.0f / (1.0f - p.pro_p);
 
-    const int row_blocks = (int)(p.M / BM);
     const int swz_tiles = (row_blocks / 8) * 8 * tiles_n;
     auto tile_origin = [&](int t, int64_t& m0, int& n0) {
         int rb, nt;
@@ -102,7 +106,8 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt
         const int k0 = it.s * BK + lc8;
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
-            const int64_t row = it.m0 + lrow + RPP * i;
+            int64_t row = it.m0 + lrow + RPP * i;
+            if constexpr (RAGGED) row = row < m_last ? row : m_last;
             ra[i] = *reinterpret_cast<const u32x4*>(p.A + row * p.K + k0);
             if constexpr (PRO == PRO_LN) { lm[i] = p.mean[row]; lr[i] = p.rstd[row]; }
         }
@@ -131,7 +136,7 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt
                 a = pack8(v);
             } else if constexpr (PRO == PRO_DROP) {
                 if (pro_th) {
-                    const uint64_t e0 = (uint64_t)(it.m0 + lrow + RPP * i) * p.K + k0;
+                    const uint64_t e0 = (uint64_t)((RAGGED ? p.row0 : 0) + it.m0 + lrow + RPP * i) * p.K + k0;
                     const f32x4 k0v = drop_keep4(p.pro_seed, e0, pro_th, pro_sc);
                     const f32x4 k1v = drop_keep4(p.pro_seed, e0 + 4, pro_th, pro_sc);
                     float v[8];
@@ -201,11 +206,13 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt
 #pragma unroll 2
                 for (int ps = 0; ps < NPS; ++ps) {
                     const int rr = ps * RPS + er;
-                    const int64_t off = (m0 + wm * (TMW * 32) + i * 32 + rr) * p.N + col;
+                    const int64_t grow = m0 + wm * (TMW * 32) + i * 32 + rr;
+                    if constexpr (RAGGED) { if (grow > m_last) continue; }
+                    const int64_t off = grow * p.N + col;
                     f32x4 v = *reinterpret_cast<const f32x4*>(stg + rr * SLD + ec) + bv;
                     f32x4 dk = {1.f, 1.f, 1.f, 1.f};
                     if constexpr (EPI == EPI_BIAS_DROP_RES || EPI == EPI_BIAS_GELU_DROP || EPI == EPI_GELU_BWD) {
-                        if (epi_th) dk = drop_keep4(p.epi_seed, (uint64_t)off, epi_th, epi_sc);
+                        if (epi_th) dk = drop_keep4(p.epi_seed, (uint64_t)(off + (RAGGED ? p.row0 * p.N : 0)), epi_th, epi_sc);
                     }
                     float o4[4] = {v.x, v.y, v.z, v.w};
                     if constexpr (EPI == EPI_BIAS_DROP_RES) {
@@ -276,6 +283,7 @@ struct TnArgsB {
     int64_t M; int N, K;
     int n_split; int64_t rows_per_split;
     uint32_t pro_seed; float pro_p;
+    int64_t row0;          // see NtArgsB
 };
 
 constexpr int TMB = 32;              // rows of M per LDS stage (two k16 steps)
@@ -291,7 +299,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* tile, int m_base, int c0
     return f;
 }
 
-template <int PRO, bool BLN>
+template <int PRO, bool BLN, bool RAGGED = false>
 __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_k(TnArgsB p) {
     __shared__ __attribute__((aligned(16))) bf16_t sm[2 * 2 * TMB * LDW];    // [buf][A|B][32][160]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -306,7 +314,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_k(TnArgsB p) {
     const int64_t r_begin = (int64_t)split * p.rows_per_split;
     const int64_t r_end = r_begin + p.rows_per_split < p.M ? r_begin + p.rows_per_split : p.M;
     if (r_begin >= r_end) return;
-    const int n_it = (int)((r_end - r_begin) / TMB);
+    const int n_it = RAGGED ? (int)((r_end - r_begin + TMB - 1) / TMB) : (int)((r_end - r_begin) / TMB);
+    const int64_t m_last = p.M - 1;
 
     const int lrow = tid >> 4, lc8 = (tid & 15) * 8;           // rows lrow + 16*i, bf16 columns lc8..lc8+7
     const uint32_t pro_th = drop_thresh(p.pro_p);
@@ -325,9 +334,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_k(TnArgsB p) {
         const int64_t r0 = r_begin + (int64_t)it * TMB + lrow;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            ra[i] = *reinterpret_cast<const u32x4*>(p.A + (r0 + 16 * i) * p.N + n0 + lc8);
-            rb[i] = *reinterpret_cast<const u32x4*>(p.B + (r0 + 16 * i) * p.K + k0 + lc8);
-            if constexpr (BLN) { bm[i] = p.mean[r0 + 16 * i]; bs[i] = p.rstd[r0 + 16 * i]; }
+            int64_t row = r0 + 16 * i;
+            if constexpr (RAGGED) row = row < m_last ? row : m_last;
+            ra[i] = *reinterpret_cast<const u32x4*>(p.A + row * p.N + n0 + lc8);
+            rb[i] = *reinterpret_cast<const u32x4*>(p.B + row * p.K + k0 + lc8);
+            if constexpr (BLN) { bm[i] = p.mean[row]; bs[i] = p.rstd[row]; }
         }
     };
     auto commit = [&](int buf, int it) {
@@ -340,12 +351,19 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_k(TnArgsB p) {
             float av[8];
             unpack8(a, av);
             if constexpr (PRO == PRO_DROP) {
-                const uint64_t e0 = (uint64_t)(r0 + 16 * i) * p.N + n0 + lc8;
+                const uint64_t e0 = (uint64_t)((RAGGED ? p.row0 : 0) + r0 + 16 * i) * p.N + n0 + lc8;
                 const f32x4 k0v = drop_keep4(p.pro_seed, e0, pro_th, pro_sc);
                 const f32x4 k1v = drop_keep4(p.pro_seed, e0 + 4, pro_th, pro_sc);
                 av[0] *= k0v.x; av[1] *= k0v.y; av[2] *= k0v.z; av[3] *= k0v.w;
                 av[4] *= k1v.x; av[5] *= k1v.y; av[6] *= k1v.z; av[7] *= k1v.w;
                 a = pack8(av);
+            }
+            if constexpr (RAGGED) {
+                if (r0 + 16 * i > m_last) {                      // rows past the end count as zero
+                    a = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) av[e] = 0.f;
+                }
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) colsum[e] += av[e];
@@ -420,19 +438,32 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_k(TnArgsB p) {
     }
 }
 
-template <int PRO, typename C>
+template <int PRO, typename C, bool RAGGED = false>
 int launch_nt_b(const NtArgsB& a, int epi, hipStream_t st) {
-    const int64_t tiles = (a.M / C::BM) * (a.N / C::BN);
+    const int64_t tiles = ((a.M + C::BM - 1) / C::BM) * (a.N / C::BN);
     const int grid = (int)(tiles < C::SLOTS ? tiles : C::SLOTS);
     switch (epi) {
-        case EPI_BIAS: gemm_nt_bf16_k<PRO, EPI_BIAS, C><<<grid, C::THREADS, 0, st>>>(a); break;
-        case EPI_BIAS_DROP_RES: gemm_nt_bf16_k<PRO, EPI_BIAS_DROP_RES, C><<<grid, C::THREADS, 0, st>>>(a); break;
-        case EPI_BIAS_GELU_DROP: gemm_nt_bf16_k<PRO, EPI_BIAS_GELU_DROP, C><<<grid, C::THREADS, 0, st>>>(a); break;
-        case EPI_GELU_BWD: gemm_nt_bf16_k<PRO, EPI_GELU_BWD, C><<<grid, C::THREADS, 0, st>>>(a); break;
-        case EPI_NONE: gemm_nt_bf16_k<PRO, EPI_NONE, C><<<grid, C::THREADS, 0, st>>>(a); break;
+        case EPI_BIAS: gemm_nt_bf16_k<PRO, EPI_BIAS, C, RAGGED><<<grid, C::THREADS, 0, st>>>(a); break;
+        case EPI_BIAS_DROP_RES: gemm_nt_bf16_k<PRO, EPI_BIAS_DROP_RES, C, RAGGED><<<grid, C::THREADS, 0, st>>>(a); break;
+        case EPI_BIAS_GELU_DROP: gemm_nt_bf16_k<PRO, EPI_BIAS_GELU_DROP, C, RAGGED><<<grid, C::THREADS, 0, st>>>(a); break;
+        case EPI_GELU_BWD: gemm_nt_bf16_k<PRO, EPI_GELU_BWD, C, RAGGED><<<grid, C::THREADS, 0, st>>>(a); break;
+        case EPI_NONE: gemm_nt_bf16_k<PRO, EPI_NONE, C, RAGGED><<<grid, C::THREADS, 0, st>>>(a); break;
         default: return HWGAT_EINVAL;
     }
     HWGAT_LAUNCH_CHECK();
+}
+
+// the same launch restricted to rows [r0, r0 + rows) of every M-indexed operand
+NtArgsB nt_rows_b(NtArgsB a, int64_t r0, int64_t rows) {
+    a.A += r0 * a.K;
+    a.C += r0 * a.N;
+    if (a.C2) a.C2 += r0 * a.N;
+    if (a.res) a.res += r0 * a.N;
+    if (a.aux) a.aux += r0 * a.N;
+    if (a.mean) { a.mean += r0; a.rstd += r0; }
+    a.M = rows;
+    a.row0 = r0;
+    return a;
 }
 
 }  // namespace
@@ -442,15 +473,30 @@ extern "C" int hwgat_linear_nt_bf16(const void* A, const void* W, const float* b
                                     const float* beta, uint32_t pro_seed, float pro_p, int epi, const void* res,
                                     void* C2, const void* aux, uint32_t epi_seed, float epi_p, void* stream) {
     if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) return HWGAT_EINVAL;
-    if (M % 128 || N % 128 || K % 64 || (M / 128) * (int64_t)(N / 128) > 0x7fffffff) return HWGAT_ESHAPE;
+    if (N % 128 || K % 64 || ((M + 127) / 128) * (int64_t)(N / 128) > 0x7fffffff) return HWGAT_ESHAPE;   // any M
     if (pro == PRO_LN && (!mean || !rstd || !gamma || !beta)) return HWGAT_EINVAL;
     if (epi == EPI_BIAS_DROP_RES && !res) return HWGAT_EINVAL;
     if (epi == EPI_BIAS_GELU_DROP && !C2) return HWGAT_EINVAL;
     if (epi == EPI_GELU_BWD && !aux) return HWGAT_EINVAL;
     if (pro_p < 0.f || pro_p >= 1.f || epi_p < 0.f || epi_p >= 1.f) return HWGAT_EINVAL;
     NtArgsB a{(const bf16_t*)A, (const bf16_t*)W, bias, (bf16_t*)C, (bf16_t*)C2, (const bf16_t*)res,
-              (const bf16_t*)aux, mean, rstd, gamma, beta, M, N, K, pro_seed, epi_seed, pro_p, epi_p};
+              (const bf16_t*)aux, mean, rstd, gamma, beta, M, N, K, pro_seed, epi_seed, pro_p, epi_p, 0};
     hipStream_t st = (hipStream_t)stream;
+    const int64_t m_bulk = M / 128 * 128;                       // ragged token count: bulk launch + RAGGED tail launch
+    if (m_bulk != M) {
+        if (m_bulk) {
+            const int rc = hwgat_linear_nt_bf16(A, W, bias, C, m_bulk, N, K, pro, mean, rstd, gamma, beta, pro_seed, pro_p,
+                                                epi, res, C2, aux, epi_seed, epi_p, stream);
+            if (rc) return rc;
+        }
+        const NtArgsB t = nt_rows_b(a, m_bulk, M - m_bulk);
+        switch (pro) {
+            case PRO_NONE: return launch_nt_b<PRO_NONE, NtB64, true>(t, epi, st);
+            case PRO_LN: return launch_nt_b<PRO_LN, NtB64, true>(t, epi, st);
+            case PRO_DROP: return launch_nt_b<PRO_DROP, NtB64, true>(t, epi, st);
+            default: return HWGAT_EINVAL;
+        }
+    }
 #define NTB_GO(P) return launch_nt_b<P, NtB64>(a, epi, st)
     switch (pro) {
         case PRO_NONE: NTB_GO(PRO_NONE);
@@ -466,8 +512,28 @@ extern "C" int hwgat_linear_tn_bf16(const void* A, const void* B, float* dW, flo
                                     const float* gamma, const float* beta, void* stream) {
     if (!A || !B || !dW || M <= 0 || N <= 0 || K <= 0) return HWGAT_EINVAL;
     if (mean && (!rstd || !gamma || !beta)) return HWGAT_EINVAL;
-    if (M % TMB || N % 128 || K % 128) return HWGAT_ESHAPE;
+    if (N % 128 || K % 128) return HWGAT_ESHAPE;                 // any M
     if (pro_p < 0.f || pro_p >= 1.f) return HWGAT_EINVAL;
+    const int64_t m_bulk = M / TMB * TMB;
+    if (m_bulk != M) {                                          // bulk launch + one RAGGED stage for the last M % 32 rows
+        if (m_bulk) {
+            const int rc = hwgat_linear_tn_bf16(A, B, dW, db, m_bulk, N, K, pro_seed, pro_p, mean, rstd, gamma, beta, stream);
+            if (rc) return rc;
+        }
+        const int64_t rows_t = M - m_bulk;
+        TnArgsB t{(const bf16_t*)A + m_bulk * N, (const bf16_t*)B + m_bulk * K, dW, db, mean ? mean + m_bulk : nullptr,
+                  mean ? rstd + m_bulk : nullptr, gamma, beta, rows_t, N, K, 1, TMB, pro_seed, pro_p, m_bulk};
+        const int grid_t = 8 * (N / 128) * (K / 128);
+        hipStream_t stt = (hipStream_t)stream;
+        if (pro_p > 0.f) {
+            if (mean) gemm_tn_bf16_k<PRO_DROP, true, true><<<grid_t, 256, 0, stt>>>(t);
+            else gemm_tn_bf16_k<PRO_DROP, false, true><<<grid_t, 256, 0, stt>>>(t);
+        } else {
+            if (mean) gemm_tn_bf16_k<PRO_NONE, true, true><<<grid_t, 256, 0, stt>>>(t);
+            else gemm_tn_bf16_k<PRO_NONE, false, true><<<grid_t, 256, 0, stt>>>(t);
+        }
+        HWGAT_LAUNCH_CHECK();
+    }
     const int n_tiles = (N / 128) * (K / 128);
     auto gcd = [](int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; };
     const int r_min = n_tiles / gcd(n_tiles, 512);
@@ -481,7 +547,7 @@ extern "C" int hwgat_linear_tn_bf16(const void* A, const void* B, float* dW, flo
     rows = (rows + TMB - 1) / TMB * TMB;
     const int n_split = (int)((M + rows - 1) / rows);
     TnArgsB a{(const bf16_t*)A, (const bf16_t*)B, dW, db, mean, rstd, gamma, beta, M, N, K, n_split, rows,
-              pro_seed, pro_p};
+              pro_seed, pro_p, 0};
     const int grid = ((n_split + 7) / 8) * 8 * n_tiles;
     hipStream_t st = (hipStream_t)stream;
     if (pro_p > 0.f) {

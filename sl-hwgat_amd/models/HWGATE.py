@@ -162,8 +162,7 @@ class Model(nn.Module):
         return [(base + (k * 4 + s) * 0xC2B2AE35) & 0xFFFFFFFF for s in range(3)]
 
     def _block(self, h, blk, n_heads, shifted, thr, k=0):
-        # fp32: any token count (the GEMM kernels handle a ragged last row block); bf16 kernels need M % 128 == 0
-        if self.fused_linears and (h.dtype == torch.float32 or (h.numel() // h.shape[-1]) % 128 == 0):
+        if self.fused_linears:           # any token count: ragged tails get their own small GEMM launch
             p = self.drop_rate if self.training else 0.0
             return fused_block(h.contiguous(), thr, blk, self._mask_bits, n_heads, shifted, p, self._seeds(k),
                                self._attn_kind)

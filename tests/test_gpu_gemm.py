@@ -207,6 +207,42 @@ def test_bf16_nt_plain_bias_ln(M, N, K):
         assert rel_err(got.float().cpu(), _b(xn.float()).double() @ Wb.double().t() + b.double()) < BT
 
 
+@pytest.mark.parametrize("M", [29, 129, 928, 128 * 3 + 77])
+def test_bf16_ragged_token_counts(M):
+    """bf16 family with M % 128 != 0: bulk launch + RAGGED tail launch, canary rows behind the outputs"""
+    N, K, p = 256, 128, 0.1
+    A, W, b = _data(M, N, K, 21 + M)
+    g = torch.Generator().manual_seed(M)
+    res = torch.randn(M, N, generator=g)
+    gamma, beta = torch.randn(K, generator=g), torch.randn(K, generator=g)
+    Ab, Wb, resb = _b(A).to(DEV), _b(W).to(DEV), _b(res).to(DEV)
+    bd = b.to(DEV)
+    Ar, Wr, resr = Ab.float().cpu().double(), Wb.float().cpu().double(), resb.float().cpu().double()
+    mean, rstd = HF.ln_stats(Ab, gamma.to(DEV), beta.to(DEV))
+    lin = Ar @ Wr.t() + b.double()
+    mask = HF.dropout_mask((M, N), 1234, p, DEV).cpu().double()
+    buf = torch.full((M + 160, N), 777.0, device=DEV, dtype=torch.bfloat16)
+    out = buf[:M]
+    HF.linear_nt(Ab, Wb, bd, epi=HF.EPI_BIAS_DROP_RES, res=resb, epi_seed=1234, epi_p=p, out=out)
+    assert rel_err(out.float().cpu(), resr + lin * mask) < BT and bool((buf[M:] == 777.0).all())
+    got = HF.linear_nt(Ab, Wb, bd, pro=HF.PRO_LN, ln=(mean, rstd, gamma.to(DEV), beta.to(DEV)))
+    lnref = torch.nn.functional.layer_norm(Ar, (K,), gamma.double(), beta.double()) @ Wr.t() + b.double()
+    assert rel_err(got.float().cpu(), lnref) < 2 * BT
+    u, h1 = HF.linear_nt(Ab, Wb, bd, epi=HF.EPI_BIAS_GELU_DROP, epi_seed=1234, epi_p=p)
+    assert rel_err(h1.float().cpu(), lin) < BT
+    dY = _b(torch.randn(M, N, generator=g)).to(DEV)
+    dW, db = torch.zeros(N, K, device=DEV), torch.zeros(N, device=DEV)
+    HF.linear_tn(dY, Ab, dW, db, pro_seed=5, pro_p=p)
+    mk = HF.dropout_mask((M, N), 5, p, DEV).cpu().double()
+    dYr = dY.float().cpu().double() * mk
+    assert rel_err(dW.cpu(), _b(dYr.float()).double().t() @ Ar) < 2 * BT
+    assert rel_err(db.cpu(), dYr.sum(0)) < BT
+    dW.zero_()
+    HF.linear_tn(dY, Ab, dW, None, ln=(mean, rstd, gamma.to(DEV), beta.to(DEV)))
+    lnA = _b(torch.nn.functional.layer_norm(Ar, (K,), gamma.double(), beta.double()).float()).double()
+    assert rel_err(dW.cpu(), dY.float().cpu().double().t() @ lnA) < 2 * BT
+
+
 @pytest.mark.parametrize("p", [0.0, 0.1])
 def test_bf16_nt_epilogues(p):
     M, N, K = 512, 256, 128
