@@ -280,6 +280,98 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_x9_256_k(const float* __restri
                 C[(m0 + wm * 128 + i * 32 + crow(r, hh)) * N + n0 + wn * 128 + j * 32 + lq] = acc[i][j][r];
 }
 
+// the same 256x256 tile with EIGHT waves (2 x 4, wave tile 128x64, two waves per SIMD): one wave's barrier waits and
+// staging instructions overlap the other's MFMAs
+__global__ __launch_bounds__(512, 2) void gemm_nt_x9_256w8_k(const float* __restrict__ A, const uint16_t* __restrict__ Wp,
+                                                             float* __restrict__ C, int64_t M, int N, int K) {
+    __shared__ __attribute__((aligned(16))) uint16_t sm[2 * BUF3];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane & 31, hh = lane >> 5;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int tiles_n = N / BN3;
+    const int64_t m0 = (int64_t)(blockIdx.x / tiles_n) * BM3;
+    const int n0 = (blockIdx.x % tiles_n) * BN3;
+    const int n_slab = K / BK2;
+    const int64_t plane_w = (int64_t)N * K;
+    // staging roles: A: rows arow + 128 i (i < 2), floats ac4..ac4+3;  W: 16-byte chunks idx = tid + 512 q of [3][256][2]
+    const int arow = tid >> 2, ac4 = (tid & 3) * 4;
+    f32x4 ra[2];
+    u32x4 rw[3];
+    auto issue = [&](int s) {
+        const int k0 = s * BK2;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) ra[i] = *reinterpret_cast<const f32x4*>(A + (m0 + arow + 128 * i) * K + k0 + ac4);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int idx = tid + 512 * q, pl = idx >> 9, rem = idx & 511, row = rem >> 1, ch = rem & 1;
+            rw[q] = *reinterpret_cast<const u32x4*>(Wp + pl * plane_w + (int64_t)(n0 + row) * K + k0 + ch * 8);
+        }
+    };
+    auto commit = [&](int buf) {
+        uint16_t* b = sm + buf * BUF3;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            uint32_t lo[3], hi[3];
+            split2(ra[i].x, ra[i].y, lo);
+            split2(ra[i].z, ra[i].w, hi);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                u32x2 v = {lo[pl], hi[pl]};
+                *reinterpret_cast<u32x2*>(b + pl * PLANE3 + (arow + 128 * i) * LDT2 + ac4) = v;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int idx = tid + 512 * q, pl = idx >> 9, rem = idx & 511, row = rem >> 1, ch = rem & 1;
+            *reinterpret_cast<u32x4*>(b + pl * PLANE3 + (BM3 + row) * LDT2 + ch * 8) = rw[q];
+        }
+    };
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    issue(0);
+    commit(0);
+    __syncthreads();
+    int buf = 0;
+    for (int s = 0; s < n_slab; ++s) {
+        const bool have_next = s + 1 < n_slab;
+        if (have_next) issue(s + 1);
+        const uint16_t* ap = sm + buf * BUF3 + (wm * 128 + lq) * LDT2 + 8 * hh;
+        const uint16_t* wp = sm + buf * BUF3 + (BM3 + wn * 64 + lq) * LDT2 + 8 * hh;
+        bf16x8 bfr[3][2], af[4];
+#pragma unroll
+        for (int pl = 2; pl >= 0; --pl)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bfr[pl][j] = *reinterpret_cast<const bf16x8*>(wp + pl * PLANE3 + j * 32 * LDT2);
+#pragma unroll
+        for (int pa = 2; pa >= 0; --pa) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(ap + pa * PLANE3 + i * 32 * LDT2);
+#pragma unroll
+            for (int pb = 2; pb >= 0; --pb)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[pb][j], acc[i][j], 0, 0, 0);
+        }
+        if (have_next) commit(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                C[(m0 + wm * 128 + i * 32 + crow(r, hh)) * N + n0 + wn * 64 + j * 32 + lq] = acc[i][j][r];
+}
+
 __global__ void split3_k(const float* __restrict__ in, uint16_t* __restrict__ out, int64_t n) {
     for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2; i < n; i += (int64_t)gridDim.x * 512) {
         uint32_t p[3];
@@ -306,7 +398,8 @@ extern "C" int hwgat_linear_nt_f32x9(const float* A, const uint16_t* W3, float* 
     static const int pin = getenv("HWGAT_X9_PIN") ? atoi(getenv("HWGAT_X9_PIN")) : 1;   // 0: compiler order (A/B)
     if (M % BM3 == 0 && N % BN3 == 0 && !small_only) {
         const int grid = (int)((M / BM3) * (N / BN3));
-        if (pin == 0) gemm_nt_x9_256_k<0><<<grid, 256, 0, (hipStream_t)stream>>>(A, W3, C, M, N, K);
+        if (pin == 8) gemm_nt_x9_256w8_k<<<grid, 512, 0, (hipStream_t)stream>>>(A, W3, C, M, N, K);
+        else if (pin == 0) gemm_nt_x9_256_k<0><<<grid, 256, 0, (hipStream_t)stream>>>(A, W3, C, M, N, K);
         else gemm_nt_x9_256_k<1><<<grid, 256, 0, (hipStream_t)stream>>>(A, W3, C, M, N, K);
     }
     else
