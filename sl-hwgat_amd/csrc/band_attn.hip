@@ -22,6 +22,7 @@
 // statistics are moved across lanes with ds_bpermute -- still no LDS tile, no barrier.
 // dK / dV of a key frame collect the contributions of query frames f-1, f, f+1 in a sliding
 // 3-frame accumulator window and are stored once.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -265,15 +266,22 @@ __global__ __launch_bounds__(256, MINW) void band_attn_fwd_k(const T* __restrict
 }
 
 // =============================================================== backward
-template <typename T, int HD, int PF, int MINW>
+// XPOSE = true: the transposed P / dS tiles (lane = key) come from a wave-private LDS scratch (one 16-byte write
+// and four 4-byte reads per tile and lane) instead of a second pair of MFMA products: 60 instead of 84 MFMAs per
+// frame, no cross-lane statistics.  XPOSE = false is the register-only form described above.
+template <typename T, int HD, int PF, int MINW, bool XPOSE>
 __global__ __launch_bounds__(256, MINW) void band_attn_bwd_k(const T* __restrict__ qkv, const T* __restrict__ dO,
                                                        T* __restrict__ dqkv,
                                                        const uint64_t* __restrict__ maskrows, BandGeom g,
                                                        int n_units) {
     constexpr int NC = HD / 16;
+    constexpr int XLD = 20;                                      // scratch row stride (floats): 16-byte aligned rows
+    __shared__ __attribute__((aligned(16))) float xsm[XPOSE ? 4 * 6 * 16 * XLD : 4];
     const int lane = threadIdx.x & 63, lr = lane & 15, gq = lane >> 4;
     // the wave index is uniform; say so, so that unit decoding and all base pointers live in SGPRs
-    const int u_raw = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* xs = xsm + (XPOSE ? wib * (6 * 16 * XLD) : 0);        // [P tiles 0..2 | dS tiles 3..5][q][XLD]
+    const int u_raw = blockIdx.x * 4 + wib;
     const bool live = u_raw < n_units;                           // tail waves shadow the last unit without storing
     const int u = live ? u_raw : n_units - 1;
     const BandUnit un = decode_band(g, u);                       // backward units always span the whole clip
@@ -379,27 +387,50 @@ __global__ __launch_bounds__(256, MINW) void band_attn_bwd_k(const T* __restrict
                             st1<T>(row + r * rs + coff + 16 * ct, acc[ct][r] * band_scale<HD>());
                 }
                 // ---- orientation 2: lane = key joint lr, registers = query joints 4g + r
-                float m2[4], l2[4], d2[4];
+                if constexpr (XPOSE) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {                                  // statistics of query joint 4g + r
-                    m2[r] = __shfl(m, 4 * gq + r, 64);
-                    l2[r] = __shfl(linv, 4 * gq + r, 64);
-                    d2[r] = __shfl(delta, 4 * gq + r, 64);
-                }
-#pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    const bool tile_ok = (t == 0) ? hp : (t == 2) ? hn : true;
-                    const f32x4v s2 = dot_rows<NC>(q.q, kw[t].k);              // S[q = 4g + r][key = lr]
-                    const f32x4v dp2 = dot_rows<NC>(q.go, kw[t].v);
-                    f32x4v p2, ds2;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const bool vis = tile_ok && ((mrow2[r] >> (16 * t + lr)) & 1ull);
-                        p2[r] = vis ? __expf(s2[r] - m2[r]) * l2[r] : 0.f;
-                        ds2[r] = p2[r] * (dp2[r] - d2[r]);
+                    for (int t = 0; t < 3; ++t) {
+                        *reinterpret_cast<f32x4v*>(xs + (t * 16 + lr) * XLD + 4 * gq) = p[t];
+                        *reinterpret_cast<f32x4v*>(xs + ((3 + t) * 16 + lr) * XLD + 4 * gq) = ds[t];
                     }
-                    mul_cols<NC>(ds2, q.qc, dk[t]);                            // dK[key][c] += sum_q dS[q][key] (scale*Q)[q][c]
-                    mul_cols<NC>(p2, q.gc, dv[t]);                             // dV[key][c] += sum_q P[q][key] dO[q][c]
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        f32x4v p2, ds2;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            p2[r] = xs[(t * 16 + 4 * gq + r) * XLD + lr];
+                            ds2[r] = xs[((3 + t) * 16 + 4 * gq + r) * XLD + lr];
+                        }
+                        mul_cols<NC>(ds2, q.qc, dk[t]);                        // dK[key][c] += sum_q dS[q][key] (scale*Q)[q][c]
+                        mul_cols<NC>(p2, q.gc, dv[t]);                         // dV[key][c] += sum_q P[q][key] dO[q][c]
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                } else {
+                    float m2[4], l2[4], d2[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {                              // statistics of query joint 4g + r
+                        m2[r] = __shfl(m, 4 * gq + r, 64);
+                        l2[r] = __shfl(linv, 4 * gq + r, 64);
+                        d2[r] = __shfl(delta, 4 * gq + r, 64);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        const bool tile_ok = (t == 0) ? hp : (t == 2) ? hn : true;
+                        const f32x4v s2 = dot_rows<NC>(q.q, kw[t].k);          // S[q = 4g + r][key = lr]
+                        const f32x4v dp2 = dot_rows<NC>(q.go, kw[t].v);
+                        f32x4v p2, ds2;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const bool vis = tile_ok && ((mrow2[r] >> (16 * t + lr)) & 1ull);
+                            p2[r] = vis ? __expf(s2[r] - m2[r]) * l2[r] : 0.f;
+                            ds2[r] = p2[r] * (dp2[r] - d2[r]);
+                        }
+                        mul_cols<NC>(ds2, q.qc, dk[t]);                        // dK[key][c] += sum_q dS[q][key] (scale*Q)[q][c]
+                        mul_cols<NC>(p2, q.gc, dv[t]);                         // dV[key][c] += sum_q P[q][key] dO[q][c]
+                    }
                 }
                 // key frame f-1 has now seen query frames f-2, f-1, f: done
                 if (hp) store_key(f - 1, dk[0], dv[0]);
@@ -472,11 +503,15 @@ extern "C" int hwgat_band_attn_bwd(const void* qkv, const void* dO, void* dqkv, 
     if (units > 0x7fffffff) return HWGAT_ESHAPE;
     hipStream_t st = (hipStream_t)stream;
     const int blocks = (int)((units + 3) / 4);
-    // PF 2 at 1 wave/SIMD 644 us, PF 2 at 2-3 waves/SIMD 630 us, PF 1 at 2 waves/SIMD 619 us: all issue-bound alike
+    // register-only form: PF 2 at 1 wave/SIMD 644 us, PF 2 at 2-3 waves/SIMD 630 us, PF 1 at 2 waves/SIMD 619 us (all issue-bound
+    // alike); with the LDS transposes (XPOSE, the default; HWGAT_BAND_XPOSE=0 selects the register-only form) 514 us
+    static const bool xpose = !(getenv("HWGAT_BAND_XPOSE") && getenv("HWGAT_BAND_XPOSE")[0] == '0');
 #define BWD_ARGS(T) (const T*)qkv, (const T*)dO, (T*)dqkv, maskrows, g, (int)units
-#define BWD(T)                                                                                  \
-    if (hd == 32) band_attn_bwd_k<T, 32, 1, 1><<<blocks, 256, 0, st>>>(BWD_ARGS(T));            \
-    else band_attn_bwd_k<T, 16, 2, 2><<<blocks, 256, 0, st>>>(BWD_ARGS(T));
+#define BWD(T)                                                                                       \
+    if (hd == 32 && xpose) band_attn_bwd_k<T, 32, 1, 1, true><<<blocks, 256, 0, st>>>(BWD_ARGS(T)); \
+    else if (hd == 32) band_attn_bwd_k<T, 32, 1, 1, false><<<blocks, 256, 0, st>>>(BWD_ARGS(T));     \
+    else if (xpose) band_attn_bwd_k<T, 16, 2, 2, true><<<blocks, 256, 0, st>>>(BWD_ARGS(T));         \
+    else band_attn_bwd_k<T, 16, 2, 2, false><<<blocks, 256, 0, st>>>(BWD_ARGS(T));
     if (dtype == HWGAT_F32) { BWD(float) }
     else if (dtype == HWGAT_BF16) { BWD(bf16_t) }
     else return HWGAT_EDTYPE;
