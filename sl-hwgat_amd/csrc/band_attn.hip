@@ -17,9 +17,11 @@
 //   K / V tiles live in a 3-frame sliding register window, so every q, k, v element is read from
 //   HBM once and every o element written once: traffic = the algorithmic 4*E*s (fwd), 7*E*s (bwd).
 //
-// Backward: the transposed tiles (lane = key) that dK / dV need are obtained by running the S and dP
-// products a second time with the operands swapped (same registers), and the per-query softmax
-// statistics are moved across lanes with ds_bpermute -- still no LDS tile, no barrier.
+// Backward: dK / dV need the P and dS tiles transposed (lane = key).  Shipped form (XPOSE): one 16-byte write
+// and four 4-byte reads per tile and lane through a 7.5 KB wave-private LDS scratch, wave-level fences only.
+// Register-only form (HWGAT_BAND_XPOSE=0): run the S and dP products a second time with the operands swapped
+// (same registers) and move the per-query softmax statistics across lanes with ds_bpermute -- 84 instead of 60
+// MFMAs per frame, 16 % slower.
 // dK / dV of a key frame collect the contributions of query frames f-1, f, f+1 in a sliding
 // 3-frame accumulator window and are stored once.
 #include <stdlib.h>
