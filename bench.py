@@ -6,8 +6,12 @@ joints -> 5 part windows (K=80), C=2, d_model=128, depths [2,2,4], 2002 classes,
 fp32, train mode with the reference defaults (dropout 0.1, stochastic attention
 drop).  Inputs are synthetic, resident in HBM before the timed region.
 
-  python bench.py [--gpus N --steps K --warmup W]          (N>1: launched by
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+  python bench.py [--gpus N --steps K --warmup W]
+
+N>1 works both ways: under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment), and as a plain `python bench.py --gpus N`,
+where this process -- before it makes any GPU call -- starts N fresh rank processes itself, relays rank 0's
+JSON line and exits non-zero if any rank fails (`spawn_ranks`).
 
 Prints ONE JSON line on rank 0 (see README / DESIGN.md section "Measurement").
 """
@@ -99,6 +103,84 @@ def cpu_baseline(sample_b=2, steps=2, hgate=False):
                       f"T={c['T']} K={K} C={c['C']} d0={c['d0']} shape, best of {steps} after 1 warm-up"}
 
 
+def spawn_ranks(n, argv):
+    """Parent side of a plain `python bench.py --gpus N` (N > 1): one fresh process per GPU, started BEFORE this
+    process has touched the GPU (it never does: it only counts devices), each with RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT in its environment -- the same contract
+    torch.distributed.run provides.  Rank 0's stdout (exactly one JSON line) is relayed to ours; everything
+    else the ranks print goes to stderr.  Any rank failing ends the others and makes this process exit non-zero."""
+    import socket
+    import subprocess
+    dry = os.environ.get("HWGAT_BENCH_DRYRUN") == "1"
+    if not dry and torch.cuda.device_count() < n:          # device_count() does not initialise HIP
+        sys.exit(f"bench.py --gpus {n}: only {torch.cuda.device_count()} GPU(s) visible on this node")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+    failed = None
+    pending = set(range(n))
+    while pending and failed is None:
+        for r in sorted(pending):
+            rc = procs[r].poll() if r else None
+            if r == 0:
+                try:                                        # rank 0 is drained so that its pipe can never fill up
+                    out0, _ = procs[0].communicate(timeout=0.2)
+                    rc = procs[0].returncode
+                except subprocess.TimeoutExpired:
+                    rc = None
+            if rc is None:
+                continue
+            pending.discard(r)
+            if rc != 0:
+                failed = (r, rc)
+                break
+        time.sleep(0.05)
+    if failed is not None:
+        for r in pending:                                   # exactly the processes started above
+            procs[r].terminate()
+        for r in pending:
+            try:
+                procs[r].wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+        sys.exit(f"bench.py: rank {failed[0]} exited with code {failed[1]}; run aborted")
+    lines = [ln for ln in out0.decode().splitlines() if ln.strip()]
+    if len(lines) != 1:
+        sys.exit(f"bench.py: rank 0 printed {len(lines)} stdout lines instead of one JSON line")
+    rec = json.loads(lines[0])
+    if rec.get("n_gpus") != n:
+        sys.exit(f"bench.py: rank 0 reports n_gpus={rec.get('n_gpus')}, expected {n}")
+    sys.stdout.write(lines[0] + "\n")
+    sys.stdout.flush()
+
+
+def dry_run(args, json_fd):
+    """HWGAT_BENCH_DRYRUN=1: the launcher / rendezvous / max-over-ranks / one-JSON-line plumbing on the gloo
+    backend with no model and no GPU (tests/test_dist_cpu.py); `value` is meaningless."""
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        dist.init_process_group("gloo")
+    if os.environ.get("HWGAT_BENCH_DRYRUN_FAIL_RANK") == str(rank):
+        sys.exit(3)
+    t = torch.tensor([0.001 * (rank + 1)], dtype=torch.float64)
+    if world > 1:
+        dist.barrier()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        out = {"metric": "dry-run", "value": 0.0, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "max_elapsed": float(t), "config": {"global_batch": world * CFG["B"], "parallelism": f"dp{world}"}}
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -120,6 +202,11 @@ def main():
                          "the PCIe-inclusive rate DESIGN.md quotes; never the headline")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return spawn_ranks(args.gpus, sys.argv[1:])         # nothing above or in there touches the GPU
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={os.environ.get('WORLD_SIZE')}")
+
     # stdout carries exactly ONE JSON line: native libraries (RCCL prints a version banner on process-group
     # init) write to file descriptor 1 directly, so fd 1 is pointed at stderr for the whole run and the
     # result line goes to the saved descriptor
@@ -130,9 +217,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if args.gpus > 1 and world == 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+    if os.environ.get("HWGAT_BENCH_DRYRUN") == "1":
+        return dry_run(args, json_fd)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist

@@ -100,3 +100,36 @@ def test_reducer_with_gradient_accumulation():
     assert all(b["pending"] == 0 for b in red.buckets)
     red.finish()
     assert torch.allclose(lin.weight.grad, torch.full((4, 8), 6.0))
+
+
+def _run_bench(extra_env, *argv):
+    import subprocess
+    env = dict(os.environ, HWGAT_BENCH_DRYRUN="1", **extra_env)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        if k not in extra_env:
+            env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=env, capture_output=True,
+                          text=True, timeout=240)
+
+
+@pytest.mark.timeout(300)
+def test_bench_parent_spawns_ranks_and_relays_one_json_line():
+    """`python bench.py --gpus 2` with no launcher: the parent starts 2 rank processes (gloo dry run: no model, no
+    GPU), relays rank 0's line, and reports the launcher-visible fields (n_gpus, global batch = 64 * N)."""
+    import json
+    res = _run_bench({}, "--gpus", "2", "--steps", "3", "--warmup", "1")
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, res.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1
+    assert rec["config"]["global_batch"] == 128 and rec["config"]["parallelism"] == "dp2"
+    assert abs(rec["max_elapsed"] - 0.002) < 1e-12          # MAX over ranks, not rank 0's own value
+
+
+@pytest.mark.timeout(300)
+def test_bench_parent_fails_when_a_rank_fails_or_the_launcher_disagrees():
+    res = _run_bench({"HWGAT_BENCH_DRYRUN_FAIL_RANK": "1"}, "--gpus", "2")
+    assert res.returncode != 0 and res.stdout.strip() == "" and "rank 1 exited with code 3" in res.stderr
+    res = _run_bench({"WORLD_SIZE": "2", "RANK": "0"}, "--gpus", "4")
+    assert res.returncode != 0 and "WORLD_SIZE=2" in res.stderr
