@@ -78,7 +78,16 @@ def sub(t):
     return t[:, ::5, ::3, ::7].contiguous().numpy()
 
 
+def probe_vectors(name, n, k=4):
+    """k fixed +-1 vectors of length n, a function of the parameter name only (tests regenerate them)"""
+    import zlib
+    rs = np.random.RandomState(zlib.crc32(name.encode()) & 0x7FFFFFFF)
+    return rs.randint(0, 2, size=(k, n)).astype(np.float64) * 2.0 - 1.0
+
+
 def grad_digest(model):
+    """per parameter: first 48 entries, (norm, sum), and 4 random +-1 projections of the WHOLE gradient
+    (a misplaced or permuted entry anywhere changes a projection)"""
     out = {}
     for name, p in model.named_parameters():
         if p.grad is None:
@@ -86,6 +95,7 @@ def grad_digest(model):
         g = p.grad.detach().double().flatten()
         out["gh." + name] = g[:48].float().numpy()
         out["gn." + name] = np.array([g.norm().item(), g.sum().item()], dtype=np.float64)
+        out["gp." + name] = probe_vectors(name, g.numel()) @ g.numpy()
     return out
 
 
@@ -191,6 +201,46 @@ def main():
           "eval.loss": np.array(loss.item())}
     fz.update({"eval." + k: v for k, v in grad_digest(model).items()})
     np.savez_compressed(os.path.join(HERE, "hd128.npz"), **fz)
+
+    # ---- F6: the BENCHMARKED shapes, one clip each (BASELINE configs[1] and configs[4]) -------------
+    # eval-mode fwd+bwd (deterministic in the reference) + one train-mode run with injected thresholds
+    for fname, (T, nW, C, d0, nc, B, seed, wstd) in {
+            "cfg2_clip.npz": (128, 5, 2, 128, 2002, 1, 14, 0.05),
+            "cfg5_clip.npz": (256, 7, 3, 256, 2002, 1, 15, 0.04)}.items():
+        model, hp, cfg = build_reference(Model, HWGATEParams, T=T, nW=nW, C=C, d0=d0, nc=nc, seed=seed, wstd=wstd)
+        x = torch.rand(B, T, nW * 16, C, generator=g)
+        y = torch.randint(0, nc, (B,), generator=g)
+        taps = {}
+        handles = []
+        blk = 0
+        for i, layer in enumerate(model.layers):
+            for j, b in enumerate(layer.blocks):
+                handles.append(b.register_forward_hook(
+                    lambda _m, _i, out, k=blk: taps.__setitem__(f"block{k}", out.detach())))
+                blk += 1
+        model.eval()
+        model.zero_grad()
+        lo = model(x)
+        loss = crit(lo, y)
+        loss.backward()
+        for h in handles:
+            h.remove()
+        fw = {"x": x.numpy(), "y": y.numpy(), "cfg": np.array([T, nW, C, d0, nc, B, seed]), "wstd": np.array(wstd),
+              "eval.logits": lo.detach().numpy(), "eval.loss": np.array(loss.item())}
+        for k, v in taps.items():
+            fw["eval." + k] = v[:, ::9, ::7, ::11].contiguous().numpy()
+        fw.update({"eval." + k: v for k, v in grad_digest(model).items()})
+        model.train()
+        thr = [0.3, 0.1, 0.5, 0.2, 0.07, 0.4, 0.25, 0.6]
+        model.zero_grad()
+        with forced_thresholds(thr):
+            lt = model(x)
+        loss = crit(lt, y)
+        loss.backward()
+        fw.update({"train.thr": np.array(thr, dtype=np.float32), "train.logits": lt.detach().numpy(),
+                   "train.loss": np.array(loss.item())})
+        fw.update({"train." + k: v for k, v in grad_digest(model).items()})
+        np.savez_compressed(os.path.join(HERE, fname), **fw)
 
     # ---- part gather (dataTransform.py:426-455) --------------------------
     from dataTransform import WindowCreate

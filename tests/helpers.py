@@ -39,6 +39,13 @@ def rel_err(a, b):
     return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
 
 
+def probe_vectors(name, n, k=4):
+    """the k fixed +-1 vectors tests/golden/make_fixtures.py::probe_vectors projects a gradient on"""
+    import zlib
+    rs = np.random.RandomState(zlib.crc32(name.encode()) & 0x7FFFFFFF)
+    return rs.randint(0, 2, size=(k, n)).astype(np.float64) * 2.0 - 1.0
+
+
 def grad_digest_check(named_grads, fx, prefix, tol):
     """compare {name: grad} with the `gh.`/`gn.` digests stored in a fixture"""
     worst = 0.0
@@ -57,6 +64,12 @@ def grad_digest_check(named_grads, fx, prefix, tol):
         worst = max(worst, e1, e2)
         assert e1 < tol, (name, "norm", e1)
         assert e2 < tol * 10, (name, "head", e2)
+        pkey = prefix + "gp." + name
+        if pkey in fx:          # +-1 projections of the WHOLE gradient: catches misplaced entries anywhere
+            proj = probe_vectors(name, gd.numel()) @ gd.numpy()
+            e3 = float(np.abs(proj - fx[pkey]).max()) / scale
+            worst = max(worst, e3)
+            assert e3 < tol * 10, (name, "projection", e3)
     assert n > 0
     return worst
 

@@ -189,7 +189,7 @@ def test_model_bf16_and_state_dict_contract():
     model.eval()
     with torch.no_grad():
         logits = model(torch.from_numpy(fx["x"]).to(DEV))
-    assert rel_err(logits.float().cpu(), fx["eval.logits"]) < 5e-2
+    assert rel_err(logits.float().cpu(), fx["eval.logits"]) < 1e-2                  # BASELINE configs[2] contract: bf16 within 1e-2 of fp32
     sd = model.state_dict()
     for k, v in fx.items():
         if k.startswith("mask."):

@@ -153,8 +153,8 @@ def test_bf16_activations_config3_tolerance():
     loss.backward()
     err = rel_err(out.float().detach().cpu(), fx["eval.logits"])
     print("bf16 logits rel err", err, "loss", loss.item(), "ref", float(fx["evalbwd.loss"]))
-    assert err < 3e-2
-    assert abs(loss.item() - float(fx["evalbwd.loss"])) < 3e-2
+    assert err < 1e-2                                        # BASELINE configs[2]: within 1e-2 of fp32
+    assert abs(loss.item() - float(fx["evalbwd.loss"])) < 1e-2 * max(1.0, float(fx["evalbwd.loss"]))
     # gradients: bf16 error accumulates through 8 blocks of backward; check norms to 10 %
     worst = 0.0
     for name, prm in model.named_parameters():
@@ -286,7 +286,6 @@ def test_wide_config_fully_fused_vs_oracle(dtype):
     g = torch.Generator().manual_seed(8)
     x = torch.rand(B, T, nW * 16, C, generator=g)
     y = torch.randint(0, nc, (B,), generator=g)
-    tol = 1e-3 if dtype == torch.float32 else 3e-2
     for thr in (None, [0.3, 0.1, 0.5, 0.2, 0.07, 0.4, 0.25, 0.6]):
         ref_p = {k: v.double().requires_grad_(k not in ("B", "pos_encoder.pe")) for k, v in params.items()}
         oracle = O.OracleHWGAT(ref_p, num_kps=nW * 16, temporal_dim=T, adj=O.window_adjacency(nW))
@@ -297,7 +296,11 @@ def test_wide_config_fully_fused_vs_oracle(dtype):
         model.zero_grad()
         out = model(x.to(DEV))
         O.smoothed_cross_entropy(out.float(), y.to(DEV)).backward()
-        assert rel_err(out.float().detach().cpu(), ref.detach()) < tol, (dtype, thr is not None)
+        # bf16: the contract's 1e-2 in eval mode; in train mode a probability within bf16 rounding of the threshold
+        # flips the selector of HWGATE.py:94-100 (a discontinuity, not an arithmetic error), hence the looser bound
+        tol = 1e-3 if dtype == torch.float32 else (1e-2 if thr is None else 3e-2)
+        assert rel_err(out.float().detach().cpu(), ref.detach()) < tol, (dtype, thr is not None, "train-mode bf16 "
+                                                                        "bound is loose only for threshold ties")
         if dtype == torch.float32 or thr is None:      # under bf16 the threshold selector may flip near ties
             for name in ("layers.2.blocks.3.ff.fc2.weight", "layers.1.blocks.1.attn.qkv.weight", "layers.0.blocks.0.norm1.weight", "head.weight"):
                 got = dict(model.named_parameters())[name].grad.double().cpu()

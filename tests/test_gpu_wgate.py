@@ -188,7 +188,7 @@ def test_model_bf16_and_seeded_dropout():
     x = torch.from_numpy(fx["x"]).to(DEV)
     with torch.no_grad():
         logits = model(x)
-    assert rel_err(logits.float().cpu(), fx["eval.logits"]) < 5e-2
+    assert rel_err(logits.float().cpu(), fx["eval.logits"]) < 1e-2                  # BASELINE configs[2] contract: bf16 within 1e-2 of fp32
     model.set_activation_dtype(torch.float32)
     model.drop_rate = 0.1
     model.train()

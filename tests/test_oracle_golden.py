@@ -91,6 +91,27 @@ def test_nw5_and_hd128_variants():
     grad_digest_check(grads, fx, "eval.", 2e-4)
 
 
+def test_benchmarked_shapes_one_clip_each():
+    """BASELINE configs[1] (T128, nW5, d0 128) and configs[4] (T256, nW7, C3, d0 256) at B=1: eval fwd+bwd,
+    block taps, and a train-threshold run, all from the reference"""
+    for name in ("cfg2_clip.npz", "cfg5_clip.npz"):
+        fx = load_fixture(name)
+        model, params, cfg = oracle_from_fixture(fx)
+        x, y = torch.from_numpy(fx["x"]), torch.from_numpy(fx["y"])
+        with torch.no_grad():
+            model.forward(x, tap=True)
+        for b in range(8):
+            assert rel_err(model.taps[f"block{b}"][:, ::9, ::7, ::11], fx[f"eval.block{b}"]) < TOL, (name, b)
+        logits, loss, grads = _grads(model, params, x, y, None)
+        assert rel_err(logits, fx["eval.logits"]) < TOL, name
+        assert abs(loss - float(fx["eval.loss"])) < 1e-5
+        grad_digest_check(grads, fx, "eval.", 2e-4)
+        if name == "cfg2_clip.npz":
+            logits, loss, grads = _grads(model, params, x, y, [float(v) for v in fx["train.thr"]])
+            assert rel_err(logits, fx["train.logits"]) < 5e-5
+            grad_digest_check(grads, fx, "train.", 5e-4)
+
+
 def test_fp64_oracle_agrees_with_fp32():
     """the fp64 instance is what GPU kernels are compared against"""
     fx = load_fixture("nw5.npz")
