@@ -282,7 +282,6 @@ def main():
         def run_step():
             xb, yb = batcher.collate(samples)
             step(xb, yb)
-            batcher.release()
     else:
         def run_step():
             step(x, y)

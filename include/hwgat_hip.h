@@ -139,15 +139,6 @@ int hwgat_band_attn_fwd(const void* qkv, void* o, const uint64_t* maskrows,
 int hwgat_band_attn_bwd(const void* qkv, const void* dO, void* dqkv, const uint64_t* maskrows,
                         int B, int F, int nW, int nH, int hd, int dtype, void* stream);
 
-/* ---- EXPERIMENT, opt-in, not used by the default path: fp32 NT product formed
- * from nine exact bf16 x bf16 partial products (x = x1 + x2 + x3, 8 significand bits each) on the bf16
- * MFMA with fp32 accumulation -- the accuracy of an fp32 FMA chain at 0.56x its matrix-pipe time.
- *   hwgat_split3_bf16      in (n) fp32 -> out (3, n) bf16 bit patterns (n even)
- *   hwgat_linear_nt_f32x9  C[M,N] = A[M,K] . W[N,K]^T, A fp32, W3 = the (3, N, K) planes of W;
- *                          M % 128 == N % 128 == K % 32 == 0; plain product only. */
-int hwgat_split3_bf16(const float* in, uint16_t* out, int64_t n, void* stream);
-int hwgat_linear_nt_f32x9(const float* A, const uint16_t* W3, float* C, int64_t M, int N, int K, void* stream);
-
 /* debug: one v_mfma_f32_16x16x4_f32 with a (16x4), b (4x16) row-major -> out (64 lanes x 4 regs) */
 int hwgat_debug_mfma16x16x4(const float* a, const float* b, float* out, void* stream);
 

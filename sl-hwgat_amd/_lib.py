@@ -34,8 +34,6 @@ _SIGS = {
     "hwgat_band_attn_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "hwgat_band_attn_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "hwgat_debug_mfma16x16x4": [_P, _P, _P, _P],
-    "hwgat_split3_bf16": [_P, _P, _L, _P],
-    "hwgat_linear_nt_f32x9": [_P, _P, _P, _L, _I, _I, _P],
     "hwgat_lnpool_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "hwgat_lnpool_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "hwgat_merge": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
@@ -56,6 +54,21 @@ def declared_symbols():
     return sorted(set(re.findall(r"\bint\s+(hwgat_\w+)\s*\(", src)))
 
 
+def _check_stamp():
+    """refuse a library that was built from other sources than the ones in the tree (a stale .so would otherwise be
+    tested and benchmarked silently): build.py writes the digest of csrc/ + the header + the flags next to the .so"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_hwgat_build", os.path.join(_HERE, "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    stamp = LIB_PATH + ".stamp"
+    have = open(stamp).read().strip() if os.path.exists(stamp) else None
+    if have != mod._digest():
+        raise RuntimeError(
+            f"{LIB_PATH} does not match the sources under sl-hwgat_amd/csrc (digest stamp "
+            f"{'missing' if have is None else 'differs'}): rebuild with `python sl-hwgat_amd/build.py`")
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -64,6 +77,7 @@ def lib():
                 f"{LIB_PATH} is missing: the HWGAT HIP backend is not built. Run "
                 "`python sl-hwgat_amd/build.py` (hipcc --offload-arch=gfx950). "
                 "There is no CPU fallback.")
+        _check_stamp()
         handle = ctypes.CDLL(LIB_PATH)
         for name, args in _SIGS.items():
             fn = getattr(handle, name)

@@ -16,7 +16,19 @@ import torch
 
 
 class PinnedBatcher:
+    """Slot reuse is ordered by events the batcher records itself; the caller has nothing to call.
+
+    Contract: `collate()` is called from the thread that enqueues the training step, and the step that consumes
+    the batch returned by call k is enqueued (on the then-current stream) before call k+1 -- which is what a
+    `DataLoader(..., collate_fn=batcher.collate, num_workers=0)` loop does.  At the start of every call an event is
+    recorded on the consumer stream; it covers everything enqueued since the previous call, i.e. the step that read
+    the slot handed out by the previous call.  Before a slot's device buffer is overwritten, the copy stream waits
+    for the event recorded one call after that slot was handed out; before a slot's pinned host buffer is
+    rewritten, the host waits for that slot's previous upload."""
+
     def __init__(self, batch_size: int, sample_shape: Tuple[int, ...], device, depth: int = 2):
+        if depth < 2:
+            raise ValueError("depth >= 2 (double buffering)")
         self.device = torch.device(device)
         self.batch_size, self.depth = batch_size, depth
         pin = self.device.type == "cuda"
@@ -27,9 +39,10 @@ class PinnedBatcher:
                      for _ in range(depth)]
         self._dev_y = [torch.empty(batch_size, dtype=torch.int64, device=self.device) for _ in range(depth)]
         self._stream = torch.cuda.Stream(self.device) if pin else None
-        self._ready = [None] * depth          # H2D done
-        self._free = [None] * depth           # consumer done with the device buffer
+        self._ready = [None] * depth          # H2D of this slot done (recorded on the copy stream)
+        self._consumed = [None] * depth       # consumer done with this slot (recorded on the consumer stream)
         self._slot = 0
+        self._last = None                     # slot handed out by the previous call
 
     def collate(self, samples: Sequence):
         """`collate_fn` for torch DataLoader: list of (array(T,J,C), label) ->
@@ -39,16 +52,23 @@ class PinnedBatcher:
         n = len(samples)
         if n > self.batch_size:
             raise ValueError("batch larger than the staging buffers")
-        if self._free[s] is not None:
-            self._free[s].synchronize()       # the step that used this slot must be done
+        if self._stream is not None and self._last is not None:
+            ev = torch.cuda.Event()           # covers the step that consumed the previous call's slot
+            ev.record(torch.cuda.current_stream(self.device))
+            self._consumed[self._last] = ev
+        if self._ready[s] is not None:
+            self._ready[s].synchronize()      # the previous upload FROM this pinned buffer must have finished
         hx, hy = self._host[s], self._host_y[s]
         for i, (x, y) in enumerate(samples):
             hx[i].copy_(torch.as_tensor(np.asarray(x), dtype=torch.float32) if not torch.is_tensor(x) else x)
             hy[i] = int(y)
+        self._last = s
         if self._stream is None:
             self._dev[s][:n].copy_(hx[:n])
             self._dev_y[s][:n].copy_(hy[:n])
             return self._dev[s][:n], self._dev_y[s][:n]
+        if self._consumed[s] is not None:
+            self._stream.wait_event(self._consumed[s])          # the step that read this device buffer is done
         with torch.cuda.stream(self._stream):
             self._dev[s][:n].copy_(hx[:n], non_blocking=True)
             self._dev_y[s][:n].copy_(hy[:n], non_blocking=True)
@@ -56,12 +76,7 @@ class PinnedBatcher:
             ev.record(self._stream)
         self._ready[s] = ev
         torch.cuda.current_stream(self.device).wait_event(ev)   # consumer stream orders after the copy
-        done = torch.cuda.Event()
-        self._free[s] = done
         return self._dev[s][:n], self._dev_y[s][:n]
 
     def release(self, slot_event_holder=None):
-        """record 'consumer finished' for the most recently returned slot (call after the step is enqueued)."""
-        s = (self._slot - 1) % self.depth
-        if self._free[s] is not None:
-            self._free[s].record(torch.cuda.current_stream(self.device))
+        """kept for callers of the first version; ordering no longer depends on it (see the class docstring)"""

@@ -348,24 +348,6 @@ def linear_nt(A, W, bias=None, *, pro=PRO_NONE, ln=None, pro_seed=0, pro_p=0.0, 
     return (C, C2) if C2 is not None else C
 
 
-def split3(W):
-    """EXPERIMENT: fp32 tensor -> (3, *W.shape) bf16 planes with W == p0 + p1 + p2 exactly (8 significand bits each)"""
-    out = torch.empty(3, *W.shape, device=W.device, dtype=torch.bfloat16)
-    call("hwgat_split3_bf16", ptr(W), ptr(out), W.numel(), stream())
-    return out
-
-
-def linear_nt_x9(A, W3, out=None):
-    """EXPERIMENT (opt-in): C = A . W^T in fp32 from nine exact bf16 partial products per element pair
-    (include/hwgat_hip.h).  W3 = split3(W)."""
-    K = A.shape[-1]
-    M = A.numel() // K
-    N = W3.shape[1]
-    C = out if out is not None else torch.empty(*A.shape[:-1], N, device=A.device, dtype=torch.float32)
-    call("hwgat_linear_nt_f32x9", ptr(A), ptr(W3), ptr(C), M, N, K, stream())
-    return C
-
-
 def linear_tn(A, Bm, dW, db=None, *, pro_seed=0, pro_p=0.0, ln=None):
     """dW[N,K] += dropmask(A)[M,N]^T . ln(Bm)[M,K]; db[N] += colsum(dropmask(A)).
     ln = (mean, rstd, gamma, beta) normalises Bm on the fly."""

@@ -21,8 +21,8 @@ def golden_dir():
 
 def pytest_sessionstart(session):
     """make sure libhwgat_hip.so matches the sources: build.py is a no-op when the digest stamp is
-    current (the normal case: the .so travels with the tree) and recompiles with hipcc otherwise.  A
-    failure here is left to surface in the tests themselves (the library loader fails loudly)."""
+    current (the normal case: the .so travels with the tree) and recompiles with hipcc otherwise.  If that
+    fails, `_lib.lib()` refuses the stale library (digest stamp check), so no test can pass on old code."""
     import importlib.util
     try:
         spec = importlib.util.spec_from_file_location("hwgat_build", os.path.join(ROOT, "sl-hwgat_amd", "build.py"))

@@ -261,10 +261,36 @@ def test_pinned_batcher_feeds_raw_joints_through_device_gather():
             a = model(ref_x[:, :, idx.long()].to(DEV))          # host-side gather (what WindowCreate does)
             model.use_part_table(idx)
             b = model(xb)                                       # device-side gather
-        batcher.release()
         assert rel_err(b.cpu(), a.cpu()) < 1e-5
         seen += n
     assert seen == 10
+
+
+def test_pinned_batcher_slot_reuse_waits_for_the_queued_consumer():
+    """two slots reused four times each with ~50 ms of work queued on the consumer stream in front of the kernel that
+    reads the batch, and NO release() call: the upload of batch n+2 must not overwrite the buffer batch n still reads"""
+    if not FUSED:
+        pytest.skip("independent of the linear path")
+    from importlib import import_module
+    col = import_module("sl-hwgat_amd.collate")
+    shape = (64, 29, 2)
+    batcher = col.PinnedBatcher(8, shape, DEV)
+    big = torch.randn(4096, 4096, device=DEV)
+    outs, labels = [], []
+    for i in range(8):
+        samples = [(torch.full(shape, float(i * 10 + j)), i * 10 + j) for j in range(8)]
+        xb, yb = batcher.collate(samples)
+        t = big
+        for _ in range(12):                         # long-running work ahead of the consumer of xb
+            t = t @ big
+            t = t / t.abs().max()
+        outs.append(xb + 0.0 * t[0, 0])             # reads xb only after the matmul chain
+        labels.append(yb.clone())
+    torch.cuda.synchronize()
+    for i in range(8):
+        want = torch.arange(8, dtype=torch.float32).view(8, 1, 1, 1) + 10 * i
+        assert torch.equal(outs[i].cpu(), want.expand(8, *shape)), i
+        assert labels[i].cpu().tolist() == [i * 10 + j for j in range(8)]
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
