@@ -151,13 +151,19 @@ def gelu(x):
 class OracleHWGAT:
     """Functional HWGAT forward driven by a reference-keyed parameter dict.
 
-    `drop_rate` is deliberately not modelled: train-mode parity is defined
-    with dropout disabled and thresholds injected (SURVEY.md §7 hard parts)."""
+    Train-mode PARITY is defined with dropout disabled and thresholds injected
+    (SURVEY.md §7 hard parts), so every test leaves `drop_rate` at 0.  A non-zero
+    `drop_rate` applies `torch.nn.functional.dropout` at the reference's four
+    sites (HWGATE.py:27, :116, :133, :135) and exists only so that `bench.py`'s
+    CPU baseline can time the reference's DEFAULT train mode (drop 0.1), whose
+    cost on a CPU is dominated by the mask generation."""
 
     def __init__(self, params: Dict[str, torch.Tensor], *, num_kps: int,
                  temporal_dim: int, depths: Sequence[int] = (2, 2, 4),
                  num_heads: Sequence[int] = (2, 4, 8), tp: int = 2,
-                 use_pe: bool = True, adj: Optional[torch.Tensor] = None):
+                 use_pe: bool = True, adj: Optional[torch.Tensor] = None,
+                 drop_rate: float = 0.0):
+        self.drop_rate = float(drop_rate)
         self.p = params
         self.K, self.T, self.tp = num_kps, temporal_dim, tp
         self.depths, self.heads = list(depths), list(num_heads)
@@ -166,6 +172,9 @@ class OracleHWGAT:
         dt = params["B"].dtype
         self.adj = (adj if adj is not None else window_adjacency(self.nW, tp)).to(dt)
         self.taps: Dict[str, torch.Tensor] = {}
+
+    def _drop(self, t):
+        return torch.nn.functional.dropout(t, self.drop_rate, True) if self.drop_rate > 0.0 else t
 
     # one PartAttentionBlock (HWGATE.py:189-221) in natural token order
     def block(self, x, i, j, nH, thr):
@@ -183,14 +192,14 @@ class OracleHWGAT:
         if shifted:
             sm = shift_mask(F, nW, tp, 1, x.dtype).view(f, nW, tp * WINDOW, tp * WINDOW)
         o, prob = window_attention(qkv[0], qkv[1], qkv[2], self.adj, sm, thr)
-        a = o @ P[pre + "attn.proj.weight"].t() + P[pre + "attn.proj.bias"]   # :115
+        a = self._drop(o @ P[pre + "attn.proj.weight"].t() + P[pre + "attn.proj.bias"])   # :115-116
         a = from_windows(a, tp)                                           # :207
         if shifted:
             a = torch.roll(a, shifts=1, dims=1)                           # :210-211
         y = x + a                                                         # :217
         h = layer_norm(y, P[pre + "norm2.weight"], P[pre + "norm2.bias"])
-        h = gelu(h @ P[pre + "ff.fc1.weight"].t() + P[pre + "ff.fc1.bias"])   # :131-132
-        h = h @ P[pre + "ff.fc2.weight"].t() + P[pre + "ff.fc2.bias"]         # :134
+        h = self._drop(gelu(h @ P[pre + "ff.fc1.weight"].t() + P[pre + "ff.fc1.bias"]))   # :131-133
+        h = self._drop(h @ P[pre + "ff.fc2.weight"].t() + P[pre + "ff.fc2.bias"])         # :134-135
         return y + h, prob                                                # :219
 
     def forward(self, x, thresholds: Optional[List[float]] = None, tap: bool = False):
@@ -201,7 +210,7 @@ class OracleHWGAT:
         if tap:
             self.taps["embed"] = h
         if self.use_pe:
-            h = h + P["pos_encoder.pe"][:, :h.shape[1]]                   # :26
+            h = self._drop(h + P["pos_encoder.pe"][:, :h.shape[1]])       # :26-27
         if tap:
             self.taps["pe"] = h
         blk = 0
