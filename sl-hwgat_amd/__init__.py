@@ -9,6 +9,7 @@ import it with importlib:
 """
 from . import _lib
 from . import functional
+from . import checkpoint
 from .parts import part_table
 from .models.HWGATE import Model
 from .models.HGATE import Model as HGATEModel
@@ -16,4 +17,4 @@ from .models.WGATE import Model as WGATEModel
 from .models.model_params import HWGATEParams, HGATEParams, WGATEParams
 
 __all__ = ["Model", "HWGATEParams", "HGATEModel", "HGATEParams", "WGATEModel", "WGATEParams", "functional",
-           "part_table", "_lib"]
+           "part_table", "_lib", "checkpoint"]
