@@ -22,6 +22,8 @@ LIB = os.path.join(HERE, "libhwgat_hip.so")
 STAMP = LIB + ".stamp"
 HEADER = os.path.join(os.path.dirname(HERE), "include", "hwgat_hip.h")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed"]
+# per-source extra flags (none at present)
+EXTRA = {}
 
 
 def sources():
@@ -33,7 +35,7 @@ def _headers():
 
 
 def _hash(paths):
-    h = hashlib.sha256(" ".join(FLAGS).encode())
+    h = hashlib.sha256((" ".join(FLAGS) + repr(sorted(EXTRA.items()))).encode())
     for f in paths:
         with open(f, "rb") as fh:
             h.update(os.path.basename(f).encode())
@@ -50,7 +52,7 @@ def _compile(src, hipcc, verbose):
     dig = _hash([src] + _headers())
     if os.path.exists(obj) and os.path.exists(obj + ".stamp") and open(obj + ".stamp").read() == dig:
         return obj, None
-    cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+    cmd = [hipcc] + FLAGS + EXTRA.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
     if verbose:
         cmd.append("-Rpass-analysis=kernel-resource-usage")
     res = subprocess.run(cmd, capture_output=True, text=True)

@@ -26,3 +26,7 @@ struct TnArgs {
 // 256x256 dW tile, 4 waves x (128x128), one wave per SIMD, pinned MFMA/memory interleave (gemm_f32_tn256.hip);
 // needs N % 256 == K % 256 == 0; fills in n_split / rows_per_split itself
 int hwgat_launch_tn256(TnArgs a, hipStream_t st);
+
+// 256x256 C tile, 4 waves x (128x128), one wave per SIMD, pinned MFMA/memory interleave (gemm_f32_nt256.hip);
+// needs M % 256 == N % 256 == K % 32 == 0; same prologues / epilogues as gemm_nt_k
+int hwgat_launch_nt256(const NtArgs& a, int pro, int epi, hipStream_t st);

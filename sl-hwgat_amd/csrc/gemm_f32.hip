@@ -502,6 +502,7 @@ extern "C" int hwgat_linear_nt_f32(const float* A, const float* W, const float* 
     if (epi == EPI_BIAS_GELU_DROP && !C2) return HWGAT_EINVAL;
     if (epi == EPI_GELU_BWD && !aux) return HWGAT_EINVAL;
     if (pro_p < 0.f || pro_p >= 1.f || epi_p < 0.f || epi_p >= 1.f) return HWGAT_EINVAL;
+    if (pro == PRO_DROP && pro_p == 0.f) pro = PRO_NONE;          // eval mode: no mask to hash
     NtArgs a{A, W, bias, C, C2, res, aux, mean, rstd, gamma, beta, M, N, K, pro_seed, epi_seed, pro_p, epi_p, 0};
     hipStream_t st = (hipStream_t)stream;
     // a token count that is not a multiple of the 128-row tile: bulk launch over the aligned rows with the
@@ -529,6 +530,28 @@ extern "C" int hwgat_linear_nt_f32(const float* A, const float* W, const float* 
     //    7-15 % faster when the epilogue is heavy (dropout+residual, GELU, GELU backward): the third
     //    block's MFMAs cover the epilogue's loads/stores.
     // (prologue-carrying launches gain nothing from K16: 570.5 vs 571.1 clips/s)
+    // Large outputs with a deep K loop: the 256x256 one-wave-per-SIMD kernel (gemm_f32_nt256.hip) over the 256-aligned
+    // rows.  Measured on the stage-2 shapes (M = 163 840, same box, tools/nt_lab.py): plain dX 131.5 -> 135.5 and
+    // 129.8 -> 131.6 TFLOP/s, LN-prologue qkv 120.6 -> 124.1, fc1 107.7 -> 111.4, GELU-backward 99.4 -> 103.8,
+    // dropout-prologue dX 110.5 -> 119.1, fc2 (K = 1024) 124.6 -> 129.3; the projection (K = 512 with the
+    // dropout + residual epilogue) is the one launch it loses (114.5 vs 117.4), and at K = 256 it loses everywhere
+    // (exposed epilogue of a lone block per CU).  HWGAT_NT_KERNEL=old keeps everything on the 128x128 kernels.
+    static const bool nt_old = [] { const char* e = getenv("HWGAT_NT_KERNEL"); return e && e[0] == 'o'; }();
+    const bool proj_like = epi == EPI_BIAS_DROP_RES && K < 1024;
+    if (!nt_old && tile_override() == 0 && N % 256 == 0 && K >= 512 && M >= 256 && !proj_like) {
+        const int64_t m256 = M / 256 * 256;
+        NtArgs b = a;
+        b.M = m256;
+        const int rc = hwgat_launch_nt256(b, pro, epi, st);
+        if (rc || m256 == M) return rc;
+        const NtArgs t = nt_rows(a, m256, M - m256);      // 128 rows left: the RAGGED instantiation hashes dropout
+        switch (pro) {                                     // masks with the global row index (row0)
+            case PRO_NONE: return launch_nt<PRO_NONE, NtSmall, true>(t, epi, st);
+            case PRO_LN: return launch_nt<PRO_LN, NtSmall, true>(t, epi, st);
+            case PRO_DROP: return launch_nt<PRO_DROP, NtSmall, true>(t, epi, st);
+            default: return HWGAT_EINVAL;
+        }
+    }
     const bool heavy = epi == EPI_BIAS_DROP_RES || epi == EPI_BIAS_GELU_DROP || epi == EPI_GELU_BWD;
     const bool big = tile_override() == 2 && (M % 256 == 0) && (N % 256 == 0);
     const bool k16 = tile_override() == 3 || (tile_override() == 0 && heavy);

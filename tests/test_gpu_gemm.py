@@ -265,7 +265,8 @@ def test_bf16_tn_weight_and_bias_grad(M, N, K, p):
     assert rel_err(dW.cpu(), dY.double().t() @ xn) < 2e-3
 
 
-# ---- the PERSISTENT tile loop of the fp32 NT kernels: more tiles than resident blocks (512 / 768 slots), so each
+# ---- the PERSISTENT tile loop of the fp32 NT kernels (gemm_nt_k: 512 / 768 resident 128x128 blocks; gemm_nt256_k,
+# N % 256 == 0 and K >= 512: 256 resident 256x256 blocks + a 128-row remainder launch): more tiles than blocks, so each
 # block walks several tiles (cross-tile slab prefetch, LayerNorm-statistics reload on a new tile, XCD-aware tile
 # order and its un-swizzled tail when the row-block count is not a multiple of 8, `t += gridDim.x`).  The headline
 # shapes run 10-30 tiles per block through exactly this path.  Checked against fp64 on sampled 128-row blocks.
@@ -274,7 +275,8 @@ _LOOP_CASES = [("none", "none"), ("none", "bias"), ("ln", "bias"), ("none", "dro
 
 
 @pytest.mark.parametrize("pro,epi", _LOOP_CASES)
-@pytest.mark.parametrize("M,N,K", [(128 * 2003, 128, 128), (128 * 701, 384, 512)])
+@pytest.mark.parametrize("M,N,K", [(128 * 2003, 128, 128), (128 * 701, 384, 512),
+                                   (256 * 301, 512, 512), (256 * 150 + 128, 256, 1024)])   # the last two: gemm_nt256_k
 def test_nt_persistent_tile_loop_every_prologue_and_epilogue(M, N, K, pro, epi):
     p = 0.1
     g = torch.Generator(device=DEV).manual_seed(M + N + len(pro) * 7 + len(epi))

@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Per-launch rates of the fp32 NT linear kernels on the HWGAT shapes (B=64 config 2), every prologue / epilogue the
+fused block uses.  Run once per kernel choice, e.g.
+    HWGAT_NT256_MINK=100000 python tools/nt_lab.py     # 128x128 kernels only (round-1 path)
+    python tools/nt_lab.py                             # default dispatch (256x256 one-wave-per-SIMD kernel where eligible)
+Prints TFLOP/s per (stage, linear, variant) and the per-step total of the 32 NT launches."""
+import importlib, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+hw = importlib.import_module("sl-hwgat_amd")
+HF = hw.functional
+dev = "cuda:0"
+B, T, K = 64, 128, 80
+stages = [int(a) for a in os.environ.get("NT_LAB_STAGES", "0,1,2").split(",")]
+reps = int(os.environ.get("NT_LAB_REPS", "8"))
+
+
+def bench(fn, n=reps):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e-3
+
+
+total = 0.0
+for i in stages:
+    d = 128 << i
+    M = B * (T >> i) * K
+    depth = (2, 2, 4)[i]
+    g = torch.Generator(device=dev).manual_seed(i)
+    def rnd(*s):
+        return torch.randn(*s, device=dev, generator=g)
+    x, y3, u2 = rnd(M, d), rnd(M, 3 * d), rnd(M, 2 * d)
+    res, aux = rnd(M, d), rnd(M, 2 * d)
+    gamma, beta = rnd(d), rnd(d)
+    mean, rstd = HF.ln_stats(x, gamma, beta)
+    w_qkv, w_p, w1, w2 = rnd(3 * d, d) * .05, rnd(d, d) * .05, rnd(2 * d, d) * .05, rnd(d, 2 * d) * .05
+    w_qkv_t, w_p_t, w1_t, w2_t = (w.t().contiguous() for w in (w_qkv, w_p, w1, w2))
+    b3, b1, b2 = rnd(3 * d), rnd(d), rnd(2 * d)
+    o3, o1, o2, o2b = torch.empty(M, 3 * d, device=dev), torch.empty(M, d, device=dev), torch.empty(M, 2 * d, device=dev), None
+    ln = (mean, rstd, gamma, beta)
+    cases = [
+        ("qkv   LN -> bias         ", M, 3 * d, d, lambda: HF.linear_nt(x, w_qkv, b3, pro=HF.PRO_LN, ln=ln, out=o3)),
+        ("proj  bias+drop+res      ", M, d, d, lambda: HF.linear_nt(x, w_p, b1, epi=HF.EPI_BIAS_DROP_RES, res=res, epi_seed=1, epi_p=.1, out=o1)),
+        ("fc1   LN -> bias+gelu+drop", M, 2 * d, d, lambda: HF.linear_nt(x, w1, b2, pro=HF.PRO_LN, ln=ln, epi=HF.EPI_BIAS_GELU_DROP, epi_seed=2, epi_p=.1, out=o2)),
+        ("fc2   bias+drop+res      ", M, d, 2 * d, lambda: HF.linear_nt(u2, w2, b1, epi=HF.EPI_BIAS_DROP_RES, res=res, epi_seed=3, epi_p=.1, out=o1)),
+        ("d_h1  drop -> gelu-bwd   ", M, 2 * d, d, lambda: HF.linear_nt(x, w2_t, None, pro=HF.PRO_DROP, pro_seed=3, pro_p=.1, epi=HF.EPI_GELU_BWD, aux=aux, epi_seed=2, epi_p=.1, out=o2)),
+        ("d_z   plain              ", M, d, 2 * d, lambda: HF.linear_nt(u2, w1_t, None, epi=HF.EPI_NONE, out=o1)),
+        ("d_o   drop -> plain      ", M, d, d, lambda: HF.linear_nt(x, w_p_t, None, pro=HF.PRO_DROP, pro_seed=1, pro_p=.1, epi=HF.EPI_NONE, out=o1)),
+        ("d_xn  plain              ", M, d, 3 * d, lambda: HF.linear_nt(y3, w_qkv_t, None, epi=HF.EPI_NONE, out=o1)),
+    ]
+    for name, m, n, k, fn in cases:
+        t = bench(fn)
+        fl = 2.0 * m * n * k
+        total += t * depth
+        print(f"stage {i} d={d:4d} {name} M={m} N={n:4d} K={k:4d}: {t * 1e6:8.1f} us  {fl / t / 1e12:6.1f} TF", flush=True)
+print(f"NT launches per step (depths 2,2,4): {total * 1e3:.2f} ms")
