@@ -175,6 +175,26 @@ int hwgat_linear_nt_f32(const float* A, const float* W, const float* bias, float
                         const float* beta, uint32_t pro_seed, float pro_p, int epi, const float* res,
                         float* C2, const float* aux, uint32_t epi_seed, float epi_p, void* stream);
 
+/* The same launch for the two linears whose OUTPUT is the input of a LayerNorm (proj -> norm2, HWGATE.py:217-219;
+ * fc2 -> the next block's norm1, :219 -> :203, through TemporalMerging :55-63 at a stage end).  Requires pro = 0,
+ * epi = 1, M % 256 == 0.  In addition to hwgat_linear_nt_f32:
+ *   stat_sum, stat_sq  (rows of the output) fp32, ZEROED by the caller: per-row sum / sum of squares of the stored
+ *                      output values are accumulated into them (hwgat_ln_finalize then yields mean / rstd), which
+ *                      removes the separate statistics pass over the tensor;
+ *   merge_K > 0        the output is stored in the TemporalMerging layout: row (b, f, k) of the (B, merge_F, merge_K, N)
+ *                      result goes to row (b, f/2, k), columns (f & 1) N .. (f & 1) N + N - 1 of a (B, merge_F/2,
+ *                      merge_K, 2N) tensor C; statistics are then per merged row (2N values).  res stays in the
+ *                      natural layout. */
+int hwgat_linear_nt_f32_ex(const float* A, const float* W, const float* bias, float* C, int64_t M, int N,
+                           int K, int pro, const float* mean, const float* rstd, const float* gamma,
+                           const float* beta, uint32_t pro_seed, float pro_p, int epi, const float* res,
+                           float* C2, const float* aux, uint32_t epi_seed, float epi_p, float* stat_sum,
+                           float* stat_sq, int merge_F, int merge_K, void* stream);
+
+/* (row sum, row sum of squares) of a d-wide tensor -> (mean, rstd) in place, nn.LayerNorm's biased variance and
+ * eps 1e-5 (HWGATE.py:162,166). */
+int hwgat_ln_finalize(float* sum_mean, float* sq_rstd, int64_t n, int d, void* stream);
+
 /* weight/bias gradient: dW[N,K] += dropmask(A)[M,N]^T . ln(B)[M,K] ; db[N] += colsum(dropmask(A))
  * (db may be NULL).  Accumulates with fp32 atomics across M slices: caller provides zeroed
  * (or to-be-accumulated-into) dW/db.  N % 128 == K % 128 == 0, any M >= 1.  pro_p == 0: no mask.

@@ -1,14 +1,16 @@
 """One PartAttentionBlock (reference hwgat/models/HWGATE.py:189-221; likewise HGATE.py:175-213) as a single autograd
 node whose forward and backward are sequences of HIP launches only.
 
-forward  (5 GEMM launches + 2 stats + 1 attention; the reference runs ~40 ATen ops):
-    stats1           = LN statistics of x                              (hwgat_ln_fwd, y=NULL)
+forward  (4 GEMM launches + 1 attention; the reference runs ~40 ATen ops):
+    stats1           = LN statistics of x: handed over by the PREVIOUS block's fc2 epilogue, or one hwgat_ln_fwd(y=NULL)
+                       pass for the first block (and whenever the epilogue cannot produce them: bf16, ragged M)
     qkv              = LN1(x) Wqkv^T + b        LN applied in the GEMM prologue
     o                = window attention(qkv)                           (hwgat_win_attn_fwd)
-    y                = x + drop(o Wp^T + b)     bias+dropout+residual in the GEMM epilogue
-    stats2           = LN statistics of y
+    y                = x + drop(o Wp^T + b)     bias+dropout+residual in the GEMM epilogue, which also accumulates the
+                       row sums / sums of squares of y -> stats2 (hwgat_linear_nt_f32_ex + hwgat_ln_finalize)
     h1, u            = LN2(y) W1^T + b ; u = drop(gelu(h1))            GEMM prologue + epilogue
-    out              = y + drop(u W2^T + b)
+    out              = y + drop(u W2^T + b)     same epilogue: statistics of `out` for the next block's LN1, and at a
+                       stage end the store goes straight to the TemporalMerging layout (HWGATE.py:55-63)
 saved for backward: x, qkv, o, y, h1, u and the row statistics (10 E floats); LN outputs and
 all dropout masks are recomputed (masks are a hash of (seed, element index)).
 
@@ -65,31 +67,48 @@ class _DwQueue:
 
 class _FusedBlock(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, thr, n1w, n1b, wqkv, bqkv, wp, bp, n2w, n2b, w1, b1, w2, b2, cfg):
-        bits, n_heads, shifted, p, seeds, kind = cfg
+    def forward(ctx, x, thr, m1, r1, n1w, n1b, wqkv, bqkv, wp, bp, n2w, n2b, w1, b1, w2, b2, cfg):
+        bits, n_heads, shifted, p, seeds, kind, want_stats, merge_out = cfg
         B, F, K, d = x.shape
         dt = x.dtype                              # fp32, or bf16 activations with fp32 master weights
         cw = (lambda w: w) if dt == torch.float32 else (lambda w: w.to(dt))
-        m1, r1 = HF.ln_stats(x, n1w, n1b)
+        fuse = HF.can_fuse_row_stats(x)           # the producing epilogue delivers the LayerNorm statistics
+        if m1 is None:
+            m1, r1 = HF.ln_stats(x, n1w, n1b)
         qkv = HF.linear_nt(x, cw(wqkv), bqkv, pro=HF.PRO_LN, ln=(m1, r1, n1w, n1b))
         o = torch.empty_like(x)
         HF.attn_fwd(kind, qkv, o, bits, thr, n_heads, shifted)
-        y = HF.linear_nt(o, cw(wp), bp, epi=HF.EPI_BIAS_DROP_RES, res=x, epi_seed=seeds[0], epi_p=p)
-        m2, r2 = HF.ln_stats(y, n2w, n2b)
+        if fuse:
+            y, m2, r2 = HF.linear_nt(o, cw(wp), bp, epi=HF.EPI_BIAS_DROP_RES, res=x, epi_seed=seeds[0], epi_p=p, stats=True)
+        else:
+            y = HF.linear_nt(o, cw(wp), bp, epi=HF.EPI_BIAS_DROP_RES, res=x, epi_seed=seeds[0], epi_p=p)
+            m2, r2 = HF.ln_stats(y, n2w, n2b)
         u, h1 = HF.linear_nt(y, cw(w1), b1, pro=HF.PRO_LN, ln=(m2, r2, n2w, n2b), epi=HF.EPI_BIAS_GELU_DROP,
                              epi_seed=seeds[1], epi_p=p)
-        out = HF.linear_nt(u, cw(w2), b2, epi=HF.EPI_BIAS_DROP_RES, res=y, epi_seed=seeds[2], epi_p=p)
+        merged = bool(merge_out and fuse)
+        if fuse and (want_stats or merged):
+            out, mo, ro = HF.linear_nt(u, cw(w2), b2, epi=HF.EPI_BIAS_DROP_RES, res=y, epi_seed=seeds[2], epi_p=p,
+                                       stats=True, merge=(F, K) if merged else None)
+        else:
+            out = HF.linear_nt(u, cw(w2), b2, epi=HF.EPI_BIAS_DROP_RES, res=y, epi_seed=seeds[2], epi_p=p)
+            mo = ro = torch.empty(0, device=x.device)
         ctx.save_for_backward(x, thr, n1w, n1b, wqkv, wp, n2w, n2b, w1, w2, m1, r1, qkv, o, y, m2, r2, h1, u)
         ctx.cfg = cfg
-        return out
+        ctx.merged = merged
+        ctx.mark_non_differentiable(mo, ro)
+        return out, mo, ro
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, _dmo, _dro):
         x, thr, n1w, n1b, wqkv, wp, n2w, n2b, w1, w2, m1, r1, qkv, o, y, m2, r2, h1, u = ctx.saved_tensors
-        bits, n_heads, shifted, p, seeds, kind = ctx.cfg
+        bits, n_heads, shifted, p, seeds, kind = ctx.cfg[:6]
         B, F, K, d = x.shape
         dt = x.dtype
         dout = dout.contiguous()
+        if ctx.merged:                            # the gradient arrives in the merged layout: back to (B, F, K, d)
+            nat = torch.empty_like(x)
+            HF.call("hwgat_merge", HF.ptr(dout), HF.ptr(nat), B, F, K, d, 1, HF.dtype_code(dout), HF.stream())
+            dout = nat
         # all 12 parameter gradients are accumulated into (split-M atomics, LN column sums): one flat
         # zero-filled buffer and views of it instead of 12 fill launches
         hid = w1.shape[0]
@@ -121,14 +140,23 @@ class _FusedBlock(torch.autograd.Function):
         # dgamma / dbeta of norm1 fall out of the same LayerNorm-backward pass)
         dx = HF.ln_backward(d_xn, x, m1, r1, n1w, d_y, dn1w, dn1b)
         dwq.join()        # every temporary above stays referenced until here, so the allocator cannot recycle it early
-        return (dx, None, dn1w, dn1b, dwqkv, dbqkv, dwp, dbp, dn2w, dn2b, dw1, db1, dw2, db2, None)
+        return (dx, None, None, None, dn1w, dn1b, dwqkv, dbqkv, dwp, dbp, dn2w, dn2b, dw1, db1, dw2, db2, None)
 
 
-def fused_block(x, thr, blk, bits, n_heads, shifted, p, seeds, kind="win"):
-    """x (B,F,K,d) fp32 contiguous; `blk` holds norm1/attn.qkv/attn.proj/norm2/ff.fc1/ff.fc2.
-    `kind`: 'win' = HWGATE part-window attention, 'blk' = HGATE block attention (thr must be None)."""
-    return _FusedBlock.apply(
-        x, thr, blk.norm1.weight, blk.norm1.bias, blk.attn.qkv.weight, blk.attn.qkv.bias,
+def fused_block(x, thr, blk, bits, n_heads, shifted, p, seeds, kind="win", stats=None, want_stats=False,
+                merge_out=False, return_stats=False):
+    """x (B,F,K,d) contiguous; `blk` holds norm1/attn.qkv/attn.proj/norm2/ff.fc1/ff.fc2.
+    `kind`: 'win' = HWGATE part-window attention, 'blk' = HGATE block attention (thr must be None).
+    `stats` = (mean, rstd) of the rows of x if the producer already has them; `want_stats`: have the fc2 epilogue produce
+    the statistics of the output rows; `merge_out`: store the output in the TemporalMerging layout (B, F/2, K, 2d)
+    (done only where the epilogue can: fp32, whole tiles -- check the returned shape).
+    Returns out, or (out, (mean, rstd) or None) with `return_stats`."""
+    m1, r1 = stats if stats is not None else (None, None)
+    out, mo, ro = _FusedBlock.apply(
+        x, thr, m1, r1, blk.norm1.weight, blk.norm1.bias, blk.attn.qkv.weight, blk.attn.qkv.bias,
         blk.attn.proj.weight, blk.attn.proj.bias, blk.norm2.weight, blk.norm2.bias,
         blk.ff.fc1.weight, blk.ff.fc1.bias, blk.ff.fc2.weight, blk.ff.fc2.bias,
-        (bits, n_heads, shifted, float(p), tuple(int(s) for s in seeds), kind))
+        (bits, n_heads, shifted, float(p), tuple(int(s) for s in seeds), kind, bool(want_stats), bool(merge_out)))
+    if not return_stats:
+        return out
+    return out, ((mo, ro) if mo.numel() else None)

@@ -48,7 +48,10 @@ using NtK16 = TileCfg<2, 2, 2, 2, 16, 3>;                      // 41 KB LDS -> 3
 // (HGATE: M = B*F*29).  It is a separate instantiation so that the bulk launch stays exactly the code
 // measured in DESIGN.md: loads clamp to the last row, stores are guarded, and dropout masks are hashed
 // with the global row index (p.row0 = first row of this launch in the full matrix).
-template <int PRO, int EPI, typename C, bool RAGGED = false>
+// STAT (EPI_BIAS_DROP_RES only): the epilogue also produces the LayerNorm statistics of its OUTPUT rows (sum and sum
+// of squares, reduced per tile in LDS, then one coalesced run of global atomics per tile) and can store in the
+// TemporalMerging layout -- see NtArgs.  It is a separate instantiation: the plain launches stay the measured code.
+template <int PRO, int EPI, typename C, bool RAGGED = false, bool STAT = false>
 __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt_k(NtArgs p) {
     constexpr int BM = C::BM, BN = C::BN, TMW = C::TMW, TNW = C::TNW, PA = C::PA, PW = C::PW, RPP = C::RPP;
     constexpr int BK = C::BK, LDT = C::LDT;
@@ -189,6 +192,12 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt
             constexpr int SLD = SW + 4, LPR = SW / 4, RPS = 64 / LPR, NPS = 32 / RPS;
             float* stg = sm + (buf ^ 1) * ((BM + BN) * LDT) + wave * (32 * SLD);
             const int er = lane / LPR, ec = (lane % LPR) * 4;
+            float* rowstat = sm + (buf ^ 1) * ((BM + BN) * LDT) + (C::THREADS / 64) * (32 * SLD);   // [BM][2] behind the staging
+            if constexpr (STAT) {
+                static_assert((C::THREADS / 64) * 32 * SLD + 2 * BM <= (BM + BN) * LDT, "no room for the row statistics");
+                for (int q = tid; q < 2 * BM; q += C::THREADS) rowstat[q] = 0.f;
+                __syncthreads();
+            }
 #pragma unroll
             for (int jc = 0; jc < TNW * 32 / SW; ++jc) {
                 const int col = n0 + wn * (TNW * 32) + jc * SW + ec;
@@ -209,7 +218,7 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt
                         const int rr = ps * RPS + er;
                         const int64_t grow = m0 + wm * (TMW * 32) + i * 32 + rr;
                         if constexpr (RAGGED) { if (grow > m_last) continue; }
-                        const int64_t off = grow * p.N + col;
+                        const int64_t off = grow * p.N + col;       // natural layout: residual, dropout hash
                         f32x4 v = *reinterpret_cast<const f32x4*>(stg + rr * SLD + ec) + bv;
                         f32x4 dk = {1.f, 1.f, 1.f, 1.f};
                         if constexpr (EPI == EPI_BIAS_DROP_RES || EPI == EPI_BIAS_GELU_DROP || EPI == EPI_GELU_BWD) {
@@ -226,10 +235,33 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt
                             v.x *= dk.x * gelu_grad(h.x); v.y *= dk.y * gelu_grad(h.y);
                             v.z *= dk.z * gelu_grad(h.z); v.w *= dk.w * gelu_grad(h.w);
                         }
-                        *reinterpret_cast<f32x4*>(p.C + off) = v;
+                        if constexpr (STAT) {
+                            float s1 = (v.x + v.y) + (v.z + v.w), s2 = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+#pragma unroll
+                            for (int o = LPR / 2; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+                            if ((lane % LPR) == 0) {
+                                const int lr = wm * (TMW * 32) + i * 32 + rr;
+                                atomicAdd(rowstat + 2 * lr, s1);
+                                atomicAdd(rowstat + 2 * lr + 1, s2);
+                            }
+                            int64_t doff = off;
+                            if (p.mg_K > 0) { int64_t mr; merge_row(grow, p.mg_F, p.mg_K, p.N, mr, doff); doff += col; }
+                            *reinterpret_cast<f32x4*>(p.C + doff) = v;
+                        } else {
+                            *reinterpret_cast<f32x4*>(p.C + off) = v;
+                        }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
+                }
+            }
+            if constexpr (STAT) {
+                __syncthreads();
+                for (int q = tid; q < BM; q += C::THREADS) {            // consecutive rows -> coalesced global atomics
+                    int64_t mr = m0 + q, doff;
+                    if (p.mg_K > 0) merge_row(m0 + q, p.mg_F, p.mg_K, p.N, mr, doff);
+                    atomicAdd(p.stat_sum + mr, rowstat[2 * q]);
+                    atomicAdd(p.stat_sq + mr, rowstat[2 * q + 1]);
                 }
             }
         }
@@ -423,6 +455,13 @@ template <int PRO, typename C, bool RAGGED = false>
 int launch_nt(const NtArgs& a, int epi, hipStream_t st) {
     const int64_t tiles = ((a.M + C::BM - 1) / C::BM) * (a.N / C::BN);
     const int grid = (int)(tiles < C::SLOTS ? tiles : C::SLOTS);      // persistent over tiles
+    if (a.stat_sum != nullptr) {                                        // validated by the caller: PRO_NONE, EPI_BIAS_DROP_RES, M % 128 == 0
+        if constexpr (PRO == PRO_NONE && !RAGGED) {
+            gemm_nt_k<PRO_NONE, EPI_BIAS_DROP_RES, C, false, true><<<grid, C::THREADS, 0, st>>>(a);
+            HWGAT_LAUNCH_CHECK();
+        }
+        return HWGAT_EINVAL;
+    }
     switch (epi) {
         case EPI_BIAS: gemm_nt_k<PRO, EPI_BIAS, C, RAGGED><<<grid, C::THREADS, 0, st>>>(a); break;
         case EPI_BIAS_DROP_RES: gemm_nt_k<PRO, EPI_BIAS_DROP_RES, C, RAGGED><<<grid, C::THREADS, 0, st>>>(a); break;
@@ -490,11 +529,12 @@ int launch_tn(TnArgs a, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int hwgat_linear_nt_f32(const float* A, const float* W, const float* bias, float* C, int64_t M,
-                                   int N, int K, int pro, const float* mean, const float* rstd,
-                                   const float* gamma, const float* beta, uint32_t pro_seed, float pro_p,
-                                   int epi, const float* res, float* C2, const float* aux, uint32_t epi_seed,
-                                   float epi_p, void* stream) {
+extern "C" int hwgat_linear_nt_f32_ex(const float* A, const float* W, const float* bias, float* C, int64_t M,
+                                      int N, int K, int pro, const float* mean, const float* rstd,
+                                      const float* gamma, const float* beta, uint32_t pro_seed, float pro_p,
+                                      int epi, const float* res, float* C2, const float* aux, uint32_t epi_seed,
+                                      float epi_p, float* stat_sum, float* stat_sq, int merge_F, int merge_K,
+                                      void* stream) {
     if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) return HWGAT_EINVAL;
     if (N % 128 || K % 32 || ((M + 127) / 128) * (int64_t)(N / 128) > 0x7fffffff) return HWGAT_ESHAPE;   // any M
     if (pro == PRO_LN && (!mean || !rstd || !gamma || !beta)) return HWGAT_EINVAL;
@@ -502,8 +542,14 @@ extern "C" int hwgat_linear_nt_f32(const float* A, const float* W, const float* 
     if (epi == EPI_BIAS_GELU_DROP && !C2) return HWGAT_EINVAL;
     if (epi == EPI_GELU_BWD && !aux) return HWGAT_EINVAL;
     if (pro_p < 0.f || pro_p >= 1.f || epi_p < 0.f || epi_p >= 1.f) return HWGAT_EINVAL;
+    const bool stat = stat_sum != nullptr || stat_sq != nullptr || merge_K > 0;
+    if (stat) {
+        if (!stat_sum || !stat_sq || pro != PRO_NONE || epi != EPI_BIAS_DROP_RES) return HWGAT_EINVAL;
+        if (M % 256) return HWGAT_ESHAPE;                          // whole tiles of either kernel only
+        if (merge_K > 0 && (merge_F <= 0 || (merge_F & 1) || M % ((int64_t)merge_F * merge_K))) return HWGAT_EINVAL;
+    }
     if (pro == PRO_DROP && pro_p == 0.f) pro = PRO_NONE;          // eval mode: no mask to hash
-    NtArgs a{A, W, bias, C, C2, res, aux, mean, rstd, gamma, beta, M, N, K, pro_seed, epi_seed, pro_p, epi_p, 0};
+    NtArgs a{A, W, bias, C, C2, res, aux, mean, rstd, gamma, beta, M, N, K, pro_seed, epi_seed, pro_p, epi_p, 0, stat_sum, stat_sq, merge_K > 0 ? merge_F : 0, merge_K > 0 ? merge_K : 0};
     hipStream_t st = (hipStream_t)stream;
     // a token count that is not a multiple of the 128-row tile: bulk launch over the aligned rows with the
     // unmodified kernels, then one small RAGGED launch for the last M % 128 rows
@@ -538,7 +584,7 @@ extern "C" int hwgat_linear_nt_f32(const float* A, const float* W, const float* 
     // (exposed epilogue of a lone block per CU).  HWGAT_NT_KERNEL=old keeps everything on the 128x128 kernels.
     static const bool nt_old = [] { const char* e = getenv("HWGAT_NT_KERNEL"); return e && e[0] == 'o'; }();
     const bool proj_like = epi == EPI_BIAS_DROP_RES && K < 1024;
-    if (!nt_old && tile_override() == 0 && N % 256 == 0 && K >= 512 && M >= 256 && !proj_like) {
+    if (!nt_old && !stat && tile_override() == 0 && N % 256 == 0 && K >= 512 && M >= 256 && !proj_like) {
         const int64_t m256 = M / 256 * 256;
         NtArgs b = a;
         b.M = m256;
@@ -563,6 +609,15 @@ extern "C" int hwgat_linear_nt_f32(const float* A, const float* W, const float* 
         default: return HWGAT_EINVAL;
     }
 #undef NT_GO
+}
+
+extern "C" int hwgat_linear_nt_f32(const float* A, const float* W, const float* bias, float* C, int64_t M,
+                                   int N, int K, int pro, const float* mean, const float* rstd,
+                                   const float* gamma, const float* beta, uint32_t pro_seed, float pro_p,
+                                   int epi, const float* res, float* C2, const float* aux, uint32_t epi_seed,
+                                   float epi_p, void* stream) {
+    return hwgat_linear_nt_f32_ex(A, W, bias, C, M, N, K, pro, mean, rstd, gamma, beta, pro_seed, pro_p, epi, res, C2, aux,
+                                  epi_seed, epi_p, nullptr, nullptr, 0, 0, stream);
 }
 
 extern "C" int hwgat_linear_tn_f32(const float* A, const float* B, float* dW, float* db, int64_t M, int N,

@@ -298,7 +298,26 @@ inline int pool_chunks(int B, int n_tok) {
     return c < maxc ? c : (maxc < 1 ? 1 : maxc);
 }
 
+// (sum, sum of squares) of the rows of a d-wide tensor, as accumulated by the producing linear's epilogue
+// (hwgat_linear_nt_f32_ex) -> (mean, rstd) in place.  Biased variance like nn.LayerNorm; E[x^2] - mean^2 in fp32 is
+// accurate to ~1e-7 (1 + mean^2 / var), ample for activations whose mean is not orders of magnitude above their spread.
+__global__ void ln_finalize_k(float* __restrict__ sum_mean, float* __restrict__ sq_rstd, int64_t n, float inv_d) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float mean = sum_mean[i] * inv_d;
+        const float var = fmaxf(sq_rstd[i] * inv_d - mean * mean, 0.f);
+        sum_mean[i] = mean;
+        sq_rstd[i] = rsqrtf(var + LN_EPS);
+    }
+}
+
 }  // namespace
+
+extern "C" int hwgat_ln_finalize(float* sum_mean, float* sq_rstd, int64_t n, int d, void* stream) {
+    if (!sum_mean || !sq_rstd || n <= 0 || d <= 0) return HWGAT_EINVAL;
+    const int grid = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    ln_finalize_k<<<grid, 256, 0, (hipStream_t)stream>>>(sum_mean, sq_rstd, n, 1.0f / d);
+    HWGAT_LAUNCH_CHECK();
+}
 
 extern "C" int hwgat_ln_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,
                             float* rstd, int64_t N, int d, int dtype, void* stream) {

@@ -125,6 +125,8 @@ class Model(nn.Module):
         self.threshold_override: Optional[List[float]] = None    # tests: inject train thresholds
         self.fused_linears = True      # hand-written f32 MFMA linears with fused LN/GELU/dropout/residual
         self._drop_calls = 0
+        self._row_stats = None         # (tensor, (mean, rstd)) handed from a block's fc2 epilogue to the next block's LN1
+        self._plan = {}                # block index -> (produce output statistics, store merged)
         if device is not None:
             self.to(device)
 
@@ -162,10 +164,19 @@ class Model(nn.Module):
         return [(base + (k * 4 + s) * 0xC2B2AE35) & 0xFFFFFFFF for s in range(3)]
 
     def _block(self, h, blk, n_heads, shifted, thr, k=0):
+        """one PartAttentionBlock.  Returns its output (B,F,K,d) -- or, for the last block of a stage when the fc2
+        epilogue can do it, already in the TemporalMerging layout (B,F/2,K,2d) (forward_features checks the shape)."""
         if self.fused_linears:           # any token count: ragged tails get their own small GEMM launch
             p = self.drop_rate if self.training else 0.0
-            return fused_block(h.contiguous(), thr, blk, self._mask_bits, n_heads, shifted, p, self._seeds(k),
-                               self._attn_kind)
+            h = h.contiguous()
+            # LayerNorm statistics of h handed over by the block that produced it, and what to ask of this one
+            rs = getattr(self, "_row_stats", None)
+            have = rs[1] if (rs is not None and rs[0] is h) else None
+            want, merge = getattr(self, "_plan", {}).get(k, (False, False))
+            out, st = fused_block(h, thr, blk, self._mask_bits, n_heads, shifted, p, self._seeds(k), self._attn_kind,
+                                  stats=have, want_stats=want, merge_out=merge, return_stats=True)
+            self._row_stats = (out, st) if st is not None else None
+            return out
         xn = HF.layer_norm(h, blk.norm1.weight, blk.norm1.bias)
         qkv = self._linear(xn, blk.attn.qkv)
         if self._attn_kind == "win":
@@ -194,6 +205,13 @@ class Model(nn.Module):
         p_pe = self.drop_rate if (self.training and self.pe) else 0.0     # Dropout lives in PositionalEncoding
         h = HF.embed(x, idx, self.B, pe, self.num_kps, self.activation_dtype, p_pe, self._seeds(63)[0])
         k = 0
+        n_blocks = sum(len(st.blocks) for st in self.layers)
+        self._row_stats = None
+        self._plan, kk = {}, 0
+        for i, stage in enumerate(self.layers):          # every block but the last feeds a LayerNorm; stage ends merge
+            for j in range(len(stage.blocks)):
+                self._plan[kk] = (kk < n_blocks - 1, j == len(stage.blocks) - 1 and i < self.num_layers - 1)
+                kk += 1
         for i, stage in enumerate(self.layers):
             for j, blk in enumerate(stage.blocks):
                 thr = None
@@ -204,8 +222,9 @@ class Model(nn.Module):
                         thr = torch.rand(1, device=x.device)      # device RNG, no host sync
                 h = self._block(h, blk, self.num_heads[i], j % 2 == 1, thr, k)
                 k += 1
-            if i < self.num_layers - 1:
-                h = HF.temporal_merge(h)
+            if i < self.num_layers - 1 and h.shape[-1] == self.embed_dim * 2 ** i:
+                h = HF.temporal_merge(h)                  # the fc2 epilogue could not store merged (bf16 / ragged M)
+        self._row_stats = None
         return HF.ln_mean_pool(h, self.norm.weight, self.norm.bias)
 
     def forward(self, x):

@@ -33,6 +33,16 @@ def sub(t):
     return t[:, ::5, ::3, ::7]
 
 
+def natural(t, d):
+    """a block output in natural token order (B,F,K,d): the last block of a stage may hand it over already in the
+    TemporalMerging layout (B,F/2,K,2d) (fc2 epilogue store, reference HWGATE.py:55-63) -- undo that for comparison"""
+    if t.shape[-1] == d:
+        return t
+    B, f, K, d2 = t.shape
+    assert d2 == 2 * d
+    return t.view(B, f, K, 2, d).permute(0, 1, 3, 2, 4).reshape(B, 2 * f, K, d)
+
+
 def rel_err(a, b):
     a = torch.as_tensor(a, dtype=torch.float64)
     b = torch.as_tensor(b, dtype=torch.float64)

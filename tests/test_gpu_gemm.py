@@ -331,3 +331,30 @@ def test_nt_persistent_tile_loop_every_prologue_and_epilogue(M, N, K, pro, epi):
     worst = max(rel_err(got[rows][i * 128:(i + 1) * 128].cpu(), ref[i * 128:(i + 1) * 128]) for i in range(len(rows) // 128))
     assert worst < 4 * tol, worst                       # no single sampled block is off
     assert bool(torch.isfinite(got).all())
+
+
+@pytest.mark.parametrize("M,N,K,F,Kt", [(256 * 6, 128, 256, 4, 96), (256 * 40, 256, 512, 8, 80), (256 * 1500, 128, 128, 6, 64000)])
+def test_nt_epilogue_row_statistics_and_merged_store(M, N, K, F, Kt):
+    """hwgat_linear_nt_f32_ex: the dropout + residual epilogue also delivers mean / rstd of its OUTPUT rows (the next
+    LayerNorm's statistics, no separate pass) and can store in the TemporalMerging layout (HWGATE.py:55-63)."""
+    p = 0.1
+    g = torch.Generator(device=DEV).manual_seed(M + N)
+    A = torch.randn(M, K, device=DEV, generator=g)
+    W = torch.randn(N, K, device=DEV, generator=g) * 0.1
+    b = torch.randn(N, device=DEV, generator=g)
+    res = torch.randn(M, N, device=DEV, generator=g) + 0.7            # a non-zero row mean
+    plain = HF.linear_nt(A, W, b, epi=HF.EPI_BIAS_DROP_RES, res=res, epi_seed=9, epi_p=p)
+    out, mean, rstd = HF.linear_nt(A, W, b, epi=HF.EPI_BIAS_DROP_RES, res=res, epi_seed=9, epi_p=p, stats=True)
+    assert torch.equal(out, plain)
+    ref = plain.double()
+    assert rel_err(mean.cpu(), ref.mean(-1).cpu()) < 1e-5
+    assert rel_err(rstd.cpu(), (ref.var(-1, unbiased=False) + 1e-5).rsqrt().cpu()) < 1e-5
+    if M % (F * Kt):
+        return
+    Bn = M // (F * Kt)
+    mg, mean2, rstd2 = HF.linear_nt(A, W, b, epi=HF.EPI_BIAS_DROP_RES, res=res, epi_seed=9, epi_p=p, stats=True, merge=(F, Kt))
+    want = plain.view(Bn, F // 2, 2, Kt, N).transpose(2, 3).reshape(Bn, F // 2, Kt, 2 * N)     # the reference's reshape
+    assert mg.shape == want.shape and torch.equal(mg, want)
+    wd = want.double().view(-1, 2 * N)
+    assert rel_err(mean2.cpu(), wd.mean(-1).cpu()) < 1e-5
+    assert rel_err(rstd2.cpu(), (wd.var(-1, unbiased=False) + 1e-5).rsqrt().cpu()) < 1e-5

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import hwgat_oracle as O
-from helpers import load_fixture, cfg_of, oracle_from_fixture, rel_err, grad_digest_check, sub
+from helpers import load_fixture, cfg_of, oracle_from_fixture, rel_err, grad_digest_check, sub, natural
 
 pytestmark = pytest.mark.gpu
 hw = importlib.import_module("sl-hwgat_amd")
@@ -63,10 +63,11 @@ def test_eval_logits_and_block_taps_cfg1():
         feat = model.forward_features(x)
     assert rel_err(logits.cpu(), fx["eval.logits"]) < TOL
     assert rel_err(feat.cpu(), fx["eval.feat"]) < TOL
+    width = [cfg["embed_dim"] * m for m in (1, 1, 2, 2, 4, 4, 4, 4)]
     for b in range(8):
-        assert rel_err(sub(taps[f"block{b}"].cpu()), fx[f"eval.block{b}"]) < TOL, b
+        assert rel_err(sub(natural(taps[f"block{b}"], width[b]).cpu()), fx[f"eval.block{b}"]) < TOL, b
     assert rel_err(taps["block0"][0, :4].cpu(), fx["eval.block0.full"]) < TOL
-    assert rel_err(taps["block1"][0, -4:].cpu(), fx["eval.block1.full"]) < TOL
+    assert rel_err(natural(taps["block1"], width[1])[0, -4:].cpu(), fx["eval.block1.full"]) < TOL
     print("eval logits rel err", rel_err(logits.cpu(), fx["eval.logits"]))
 
 
