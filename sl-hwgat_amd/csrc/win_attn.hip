@@ -23,6 +23,7 @@
 // HBM traffic is exactly the algorithmic 4*E*s (fwd) / 7*E*s (bwd): every q,k,v
 // (and dO) element is read once, every o (dq,dk,dv) element written once; all
 // rows are 128-byte-line aligned segments of hd*s bytes.
+#include <stdlib.h>
 #include "attn_common.h"
 
 namespace {
@@ -317,6 +318,155 @@ __global__ __launch_bounds__(WAVES * 64, 1) void win_attn_bwd_k(const T* __restr
     }
 }
 
+// =============================================================== backward, head_dim 128: two waves per unit
+// With hd = 128 one wave needs 4 x 32 x 132 floats = 66 KiB of LDS for its Q, K, dO, V tiles: two waves per CU, i.e.
+// two of the four matrix pipes idle and nothing to hide a wave's load / softmax / store phases behind (measured
+// 0.52 of the HBM roof in fp32 and 0.26 with bf16 storage, where the 320 MFMAs of a unit are the whole cost).
+// Here the two waves of a 128-thread workgroup SHARE a unit by head-dim halves: wave w owns columns
+// [64 w, 64 w + 64) of Q, K, V, dO (34 KiB of tiles, as in the hd = 64 kernel -> four waves per CU).  The two
+// products that contract over head_dim, S = (scale Q) K^T and dP = dO V^T, are formed as per-half partial sums and
+// exchanged through an 8 KiB LDS mailbox (a + b on one side, b + a on the other: bit-identical, so both waves
+// run the same softmax); dQ, dK, dV split by columns and need no reduction.  160 MFMAs per wave and unit.
+template <typename T, bool TRAIN>
+__global__ __launch_bounds__(128, 2) void win_attn_bwd_split_k(const T* __restrict__ qkv, const T* __restrict__ dO,
+                                                               T* __restrict__ dqkv,
+                                                               const uint32_t* __restrict__ maskbits,
+                                                               const float* __restrict__ thr_p, WinGeom g,
+                                                               int n_units) {
+    constexpr int HD = 128, HW = 64, LDW = HW + 4, NT = HW / 32;
+    constexpr int EPV = io<T>::EPV;
+    constexpr int CPR = HW / EPV, RPI = 64 / CPR, NLD = 32 / RPI;
+    constexpr int TW = 34;
+    static_assert(2 * 32 * TW <= 32 * LDW, "transpose scratch must fit the dead V tile");
+    constexpr int PER_WAVE = 4 * 32 * LDW;
+    __shared__ __attribute__((aligned(16))) float smem[2 * PER_WAVE + 2 * 1024];       // 77 824 B -> two workgroups per CU
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int lq = lane & 31, hh = lane >> 5;
+    float* Qs = smem + wave * PER_WAVE;
+    float* Ks = Qs + 32 * LDW;
+    float* Gs = Ks + 32 * LDW;
+    float* Vs = Gs + 32 * LDW;
+    float* Pt = Vs;                                            // [q][key], stride TW (V is dead by then)
+    float* Dt = Pt + 32 * TW;
+    float* mine = smem + 2 * PER_WAVE + wave * 1024;           // mailbox: register quad r4 of lane l at [r4][l][4]
+    const float* theirs = smem + 2 * PER_WAVE + (wave ^ 1) * 1024;
+    const int crow_l = lane / CPR, ccol = (lane % CPR) * EPV;
+    const int col0 = wave * HW;
+    const int64_t row3d = 3 * (int64_t)g.d;
+    const float thr = TRAIN ? *thr_p : 0.f;
+
+    int u = blockIdx.x;
+    if (u >= n_units) return;                                  // whole workgroup: both waves share u
+
+    u32x4 qr[NLD], kr[NLD], vr[NLD], gr[NLD];
+    auto issue = [&](const Unit& un) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int64_t tk = tok_of(un, i * RPI + crow_l);
+            const T* p = qkv + tk * row3d + un.head * HD + col0 + ccol;
+            qr[i] = *reinterpret_cast<const u32x4*>(p);
+            kr[i] = *reinterpret_cast<const u32x4*>(p + g.d);
+            vr[i] = *reinterpret_cast<const u32x4*>(p + 2 * g.d);
+            gr[i] = *reinterpret_cast<const u32x4*>(dO + tk * (int64_t)g.d + un.head * HD + col0 + ccol);
+        }
+    };
+    // partial 32x32 product of this wave + the other wave's, through the mailbox (callers place the barriers)
+    auto post = [&](const f32x16& t) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 v = {t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]};
+            *reinterpret_cast<f32x4*>(mine + q * 256 + lane * 4) = v;
+        }
+    };
+    auto collect = [&](const f32x16& t, float (&out)[16]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(theirs + q * 256 + lane * 4);
+            out[4 * q] = t[4 * q] + v.x; out[4 * q + 1] = t[4 * q + 1] + v.y;
+            out[4 * q + 2] = t[4 * q + 2] + v.z; out[4 * q + 3] = t[4 * q + 3] + v.w;
+        }
+    };
+    Unit cur = decode_unit(g, u);
+    issue(cur);
+
+    for (; u < n_units; u += gridDim.x) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int off = (i * RPI + crow_l) * LDW + ccol;
+            chunk<T>::to_lds(Qs + off, qr[i], qk_scale<HD>());
+            chunk<T>::to_lds(Ks + off, kr[i], 1.0f);
+            chunk<T>::to_lds(Vs + off, vr[i], 1.0f);
+            chunk<T>::to_lds(Gs + off, gr[i], 1.0f);
+        }
+        const uint32_t mbits = maskbits[cur.mrow + lq];
+        const int un = u + gridDim.x;
+        Unit nxt = cur;
+        if (un < n_units) { nxt = decode_unit(g, un); issue(nxt); }
+        lds_fence();
+
+        // S over the full head_dim = this half + the other half
+        float s[16], p[16], ds[16], dp[16];
+        {
+            const f32x16 st = tile_xyT<HW, LDW>(Ks, Qs, lq, hh);
+            post(st);
+            __syncthreads();
+            collect(st, s);
+        }
+        const uint32_t nz = masked_softmax<TRAIN>(s, p, mbits, hh, thr);
+        // dP^T[key][q] = V dO^T, likewise
+        {
+            const f32x16 dt = tile_xyT<HW, LDW>(Vs, Gs, lq, hh);
+            __syncthreads();                                  // the other wave has read S from the mailbox
+            post(dt);
+            __syncthreads();
+            collect(dt, dp);
+            float delta = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) delta += p[r] * dp[r];
+            delta += partner(delta);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ds[r] = ((nz >> r) & 1u) ? p[r] * (dp[r] - delta) : 0.f;
+        }
+        lds_fence();                                          // this wave's V tile is dead from here on
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            float* pp = Pt + lq * TW + 8 * gq + 4 * hh;
+            float* dd = Dt + lq * TW + 8 * gq + 4 * hh;
+            f32x2 a0 = {p[4 * gq], p[4 * gq + 1]}, a1 = {p[4 * gq + 2], p[4 * gq + 3]};
+            f32x2 b0 = {ds[4 * gq], ds[4 * gq + 1]}, b1 = {ds[4 * gq + 2], ds[4 * gq + 3]};
+            reinterpret_cast<f32x2*>(pp)[0] = a0; reinterpret_cast<f32x2*>(pp)[1] = a1;
+            reinterpret_cast<f32x2*>(dd)[0] = b0; reinterpret_cast<f32x2*>(dd)[1] = b1;
+        }
+        lds_fence();
+
+        f32x16 acc[NT];
+        T* gq_base = dqkv + cur.head * HD + col0 + lq * NT;
+        auto store_acc = [&](T* base, float mul) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float ov[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) ov[nt] = acc[nt][r] * mul;
+                store_nt<T, NT>(base + tok_of(cur, crow(r, hh)) * row3d, ov);
+            }
+        };
+        tile_ay<HW, LDW>(ds, Ks, lq, hh, acc);                 // dQ[:, half] = scale * dS K[:, half]
+        store_acc(gq_base, qk_scale<HD>());
+        float a[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[r] = Dt[crow(r, hh) * TW + lq];
+        tile_ay<HW, LDW>(a, Qs, lq, hh, acc);                  // dK[:, half] = dS^T (scale Q)[:, half]
+        store_acc(gq_base + g.d, 1.0f);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[r] = Pt[crow(r, hh) * TW + lq];
+        tile_ay<HW, LDW>(a, Gs, lq, hh, acc);                  // dV[:, half] = P^T dO[:, half]
+        store_acc(gq_base + 2 * g.d, 1.0f);
+        __syncthreads();                                      // mailbox (dP) read by both before the next unit posts S
+        cur = nxt;
+    }
+}
+
 __global__ void mfma_probe_k(const float* a, const float* b, float* out) {
     const int lane = threadIdx.x;
     f32x16 acc;
@@ -417,6 +567,17 @@ int launch_fwd(const void* qkv, void* o, const uint32_t* mb, const float* thr, W
 template <typename T, int HD>
 int launch_bwd(const void* qkv, const void* dO, void* dqkv, const uint32_t* mb, const float* thr,
                WinGeom g, int n_units, hipStream_t st) {
+    if constexpr (HD == 128) {                               // two waves per unit, four waves per CU (see win_attn_bwd_split_k)
+        static const bool whole = [] { const char* e = getenv("HWGAT_ATTN_SPLIT"); return e && e[0] == '0'; }();
+        if (!whole) {
+            const int blocks = min(n_units, 256 * 2);
+            if (thr)
+                win_attn_bwd_split_k<T, true><<<blocks, 128, 0, st>>>((const T*)qkv, (const T*)dO, (T*)dqkv, mb, thr, g, n_units);
+            else
+                win_attn_bwd_split_k<T, false><<<blocks, 128, 0, st>>>((const T*)qkv, (const T*)dO, (T*)dqkv, mb, thr, g, n_units);
+            HWGAT_LAUNCH_CHECK();
+        }
+    }
     constexpr int WAVES = HD <= 64 ? 4 : 2;                  // 4 x 34 KiB or 2 x 66 KiB of LDS per CU
     const int blocks = min((n_units + WAVES - 1) / WAVES, 256);
     if (thr)

@@ -241,3 +241,42 @@ def test_full_size_properties_config2():
     g2 = torch.randn(B, F, K, d, device=DEV, generator=g)
     HF.window_attention(x, bits, None, nH, True).backward(g2)
     assert x.grad[..., :d].abs().max() < 1e-3
+
+
+def test_full_size_properties_config5_head_dim_128():
+    """BASELINE config 5 shape of one micro-batch (B16 T256 K112 d256, head_dim 128): the two-waves-per-unit backward
+    (head-dim halves, S / dP partial sums exchanged through LDS) against size-independent properties, a sampled clip
+    against the oracle, and against the one-wave kernel it replaces (HWGAT_ATTN_SPLIT=0 is read once per process, so
+    the comparison is by value through the oracle, not by switching kernels)."""
+    B, F, nW, nH, hd = 16, 256, 7, 2, 128
+    d, K = nH * hd, nW * 16
+    g = torch.Generator(device=DEV).manual_seed(3)
+    qkv = torch.randn(B, F, K, 3 * d, device=DEV, generator=g)
+    bits = HF.mask_bits(O.window_adjacency(nW)).to(DEV)
+    # dO == 1: dV sums to 32 per window and channel (columns of P^T sum over 32 queries of rows that sum to 1)
+    x = qkv.clone().requires_grad_(True)
+    HF.window_attention(x, bits, None, nH, False).sum().backward()
+    per_window = x.grad[..., 2 * d:].view(B, F // 2, 2, nW, 16, d).sum(dim=(2, 4))
+    assert (per_window - 32).abs().max() < 1e-3
+    # rows of dS sum to zero: identical keys -> dq == 0 for any dO
+    x = qkv.clone()
+    x[..., d:2 * d] = 1.0
+    x.requires_grad_(True)
+    g2 = torch.randn(B, F, K, d, device=DEV, generator=g)
+    HF.window_attention(x, bits, None, nH, True).backward(g2)
+    assert x.grad[..., :d].abs().max() < 1e-3
+    # a sampled clip, train-mode threshold, shifted: all three gradients vs the fp64 oracle
+    for shifted, thr in ((False, None), (True, 0.07)):
+        xs = qkv[5:6, :6].contiguous().requires_grad_(True)
+        gs = g2[5:6, :6].contiguous()
+        tt = None if thr is None else torch.tensor([thr], device=DEV)
+        HF.window_attention(xs, bits, tt, nH, shifted).backward(gs)
+        xr = qkv[5:6, :6].cpu().double().requires_grad_(True)
+        _oracle_attn(xr, O.window_adjacency(nW), nH, shifted, thr).backward(gs.cpu().double())
+        assert rel_err(xs.grad.cpu(), xr.grad) < F32_TOL, (shifted, thr)
+    # bf16 storage
+    xb = qkv[:2].to(torch.bfloat16).requires_grad_(True)
+    HF.window_attention(xb, bits, None, nH, False).backward(g2[:2].to(torch.bfloat16))
+    xr = qkv[:2, :4].to(torch.bfloat16).cpu().double().requires_grad_(True)
+    _oracle_attn(xr, O.window_adjacency(nW), nH, False, None).backward(g2[:2, :4].to(torch.bfloat16).cpu().double())
+    assert rel_err(xb.grad[:, :4].float().cpu(), xr.grad) < 1e-2

@@ -13,6 +13,7 @@ dev = "cuda:0"
 B, T, K = 64, 128, 80
 stages = [int(a) for a in os.environ.get("NT_LAB_STAGES", "0,1,2").split(",")]
 reps = int(os.environ.get("NT_LAB_REPS", "8"))
+dt = torch.bfloat16 if os.environ.get("NT_LAB_DTYPE", "f32") == "bf16" else torch.float32
 
 
 def bench(fn, n=reps):
@@ -36,14 +37,18 @@ for i in stages:
     g = torch.Generator(device=dev).manual_seed(i)
     def rnd(*s):
         return torch.randn(*s, device=dev, generator=g)
-    x, y3, u2 = rnd(M, d), rnd(M, 3 * d), rnd(M, 2 * d)
-    res, aux = rnd(M, d), rnd(M, 2 * d)
+    def act(*s):
+        return torch.randn(*s, device=dev, generator=g).to(dt)
+    x, y3, u2 = act(M, d), act(M, 3 * d), act(M, 2 * d)
+    res, aux = act(M, d), act(M, 2 * d)
     gamma, beta = rnd(d), rnd(d)
     mean, rstd = HF.ln_stats(x, gamma, beta)
-    w_qkv, w_p, w1, w2 = rnd(3 * d, d) * .05, rnd(d, d) * .05, rnd(2 * d, d) * .05, rnd(d, 2 * d) * .05
+    w_qkv, w_p, w1, w2 = ((rnd(*s) * .05).to(dt) for s in ((3 * d, d), (d, d), (2 * d, d), (d, 2 * d)))
     w_qkv_t, w_p_t, w1_t, w2_t = (w.t().contiguous() for w in (w_qkv, w_p, w1, w2))
     b3, b1, b2 = rnd(3 * d), rnd(d), rnd(2 * d)
-    o3, o1, o2, o2b = torch.empty(M, 3 * d, device=dev), torch.empty(M, d, device=dev), torch.empty(M, 2 * d, device=dev), None
+    o3, o1, o2, o2b = (torch.empty(M, 3 * d, device=dev, dtype=dt), torch.empty(M, d, device=dev, dtype=dt),
+                       torch.empty(M, 2 * d, device=dev, dtype=dt), None)
+    esz = 2 if dt == torch.bfloat16 else 4
     ln = (mean, rstd, gamma, beta)
     cases = [
         ("qkv   LN -> bias         ", M, 3 * d, d, lambda: HF.linear_nt(x, w_qkv, b3, pro=HF.PRO_LN, ln=ln, out=o3)),
@@ -59,5 +64,7 @@ for i in stages:
         t = bench(fn)
         fl = 2.0 * m * n * k
         total += t * depth
-        print(f"stage {i} d={d:4d} {name} M={m} N={n:4d} K={k:4d}: {t * 1e6:8.1f} us  {fl / t / 1e12:6.1f} TF", flush=True)
+        mult = {"qkv ": 4, "proj": 3, "fc1 ": 5, "fc2 ": 4, "d_h1": 5, "d_z ": 3, "d_o ": 2, "d_xn": 4}[name[:4].ljust(4)]      # E-sized streams
+        gb = mult * m * d * esz
+        print(f"stage {i} d={d:4d} {name} M={m} N={n:4d} K={k:4d}: {t * 1e6:8.1f} us  {fl / t / 1e12:6.1f} TF  {gb / t / 1e12:5.2f} TB/s", flush=True)
 print(f"NT launches per step (depths 2,2,4): {total * 1e3:.2f} ms")
