@@ -180,22 +180,35 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
     };
-    // epilogue through an idle LDS buffer (fp32 staging, 32 x SW per wave), then row-wise 8 B/lane bf16 stores
+    // epilogue through an idle LDS buffer (fp32 staging, 32 x SW per wave), then row-wise 16 B/lane bf16 stores
+    // (8 columns per lane).  The residual / pre-activation operand of a whole piece is requested BEFORE the piece is
+    // parked: all its passes are in flight together instead of one HBM round trip per pass (PMC on the GELU-backward
+    // launch: waves parked in s_waitcnt 52 % of the time at 2.1 TB/s; the plain product on the same shape streams 5).
     auto epilogue = [&](int64_t m0, int n0, int idle) {
         const uint32_t epi_th = drop_thresh(p.epi_p);
         const float epi_sc = 1.0f / (1.0f - p.epi_p);
         constexpr int SW = ((BM + BN) * LDT * 2 >= (C::THREADS / 64) * 32 * 68 * 4) ? 64 : 32;
-        constexpr int SLD = SW + 4, LPR = SW / 4, RPS = 64 / LPR, NPS = 32 / RPS;
+        constexpr int SLD = SW + 4, LPR = SW / 8, RPS = 64 / LPR, NPS = 32 / RPS;
         float* stg = reinterpret_cast<float*>(sm + idle * ((BM + BN) * LDT)) + wave * (32 * SLD);
-        const int er = lane / LPR, ec = (lane % LPR) * 4;
+        const int er = lane / LPR, ec = (lane % LPR) * 8;
 #pragma unroll
         for (int jc = 0; jc < TNW * 32 / SW; ++jc) {
             const int col = n0 + wn * (TNW * 32) + jc * SW + ec;
-            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            f32x4 bv0 = {0.f, 0.f, 0.f, 0.f}, bv1 = bv0;
             if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_DROP_RES || EPI == EPI_BIAS_GELU_DROP)
-                if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + col);
+                if (p.bias) { bv0 = *reinterpret_cast<const f32x4*>(p.bias + col); bv1 = *reinterpret_cast<const f32x4*>(p.bias + col + 4); }
 #pragma unroll
             for (int i = 0; i < TMW; ++i) {
+                u32x4 ex[NPS];
+                if constexpr (EPI == EPI_BIAS_DROP_RES || EPI == EPI_GELU_BWD) {
+                    const bf16_t* src = EPI == EPI_BIAS_DROP_RES ? p.res : p.aux;
+#pragma unroll
+                    for (int ps = 0; ps < NPS; ++ps) {
+                        int64_t grow = m0 + wm * (TMW * 32) + i * 32 + ps * RPS + er;
+                        if constexpr (RAGGED) grow = grow < m_last ? grow : m_last;
+                        ex[ps] = *reinterpret_cast<const u32x4*>(src + grow * p.N + col);
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < SW / 32; ++j)
 #pragma unroll
@@ -203,38 +216,42 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt
                         stg[crow(r, hh) * SLD + j * 32 + lq] = acc[i][jc * (SW / 32) + j][r];
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-#pragma unroll 2
+#pragma unroll
                 for (int ps = 0; ps < NPS; ++ps) {
                     const int rr = ps * RPS + er;
                     const int64_t grow = m0 + wm * (TMW * 32) + i * 32 + rr;
                     if constexpr (RAGGED) { if (grow > m_last) continue; }
                     const int64_t off = grow * p.N + col;
-                    f32x4 v = *reinterpret_cast<const f32x4*>(stg + rr * SLD + ec) + bv;
-                    f32x4 dk = {1.f, 1.f, 1.f, 1.f};
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + rr * SLD + ec) + bv0;
+                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + rr * SLD + ec + 4) + bv1;
+                    float o8[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                    float dk[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
                     if constexpr (EPI == EPI_BIAS_DROP_RES || EPI == EPI_BIAS_GELU_DROP || EPI == EPI_GELU_BWD) {
-                        if (epi_th) dk = drop_keep4(p.epi_seed, (uint64_t)(off + (RAGGED ? p.row0 * p.N : 0)), epi_th, epi_sc);
+                        if (epi_th) {
+                            const uint64_t e0 = (uint64_t)(off + (RAGGED ? p.row0 * p.N : 0));
+                            const f32x4 k0 = drop_keep4(p.epi_seed, e0, epi_th, epi_sc), k1 = drop_keep4(p.epi_seed, e0 + 4, epi_th, epi_sc);
+                            dk[0] = k0.x; dk[1] = k0.y; dk[2] = k0.z; dk[3] = k0.w; dk[4] = k1.x; dk[5] = k1.y; dk[6] = k1.z; dk[7] = k1.w;
+                        }
                     }
-                    float o4[4] = {v.x, v.y, v.z, v.w};
                     if constexpr (EPI == EPI_BIAS_DROP_RES) {
-                        float rs[4];
-                        io<bf16_t>::load4(p.res + off, rs);
-                        o4[0] = rs[0] + v.x * dk.x; o4[1] = rs[1] + v.y * dk.y;
-                        o4[2] = rs[2] + v.z * dk.z; o4[3] = rs[3] + v.w * dk.w;
-                    } else if constexpr (EPI == EPI_BIAS_GELU_DROP) {
-                        io<bf16_t>::store4(p.C2 + off, o4);
-                        // gelu is evaluated on the bf16-rounded pre-activation that backward will see
-                        float h[4];
+                        float rs[8];
+                        unpack8(ex[ps], rs);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) h[e] = (float)(bf16_t)o4[e];
-                        o4[0] = gelu_f(h[0]) * dk.x; o4[1] = gelu_f(h[1]) * dk.y;
-                        o4[2] = gelu_f(h[2]) * dk.z; o4[3] = gelu_f(h[3]) * dk.w;
+                        for (int e = 0; e < 8; ++e) o8[e] = rs[e] + o8[e] * dk[e];
+                    } else if constexpr (EPI == EPI_BIAS_GELU_DROP) {
+                        const u32x4 pre = pack8(o8);
+                        *reinterpret_cast<u32x4*>(p.C2 + off) = pre;
+                        float h[8];
+                        unpack8(pre, h);                       // gelu on the bf16-rounded pre-activation that backward will see
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o8[e] = gelu_f(h[e]) * dk[e];
                     } else if constexpr (EPI == EPI_GELU_BWD) {
-                        float h[4];
-                        io<bf16_t>::load4(p.aux + off, h);
-                        o4[0] = v.x * dk.x * gelu_grad(h[0]); o4[1] = v.y * dk.y * gelu_grad(h[1]);
-                        o4[2] = v.z * dk.z * gelu_grad(h[2]); o4[3] = v.w * dk.w * gelu_grad(h[3]);
+                        float h[8];
+                        unpack8(ex[ps], h);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o8[e] = o8[e] * dk[e] * gelu_grad(h[e]);
                     }
-                    io<bf16_t>::store4(p.C + off, o4);
+                    *reinterpret_cast<u32x4*>(p.C + off) = pack8(o8);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();

@@ -206,6 +206,20 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt
                     if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + col);
 #pragma unroll
                 for (int i = 0; i < TMW; ++i) {
+                    // the piece's residual / pre-activation operand: ALL its passes are requested before the piece is
+                    // parked, so NPS loads per lane are in flight together (they used to be issued pass by pass, two
+                    // at a time, each paying an HBM round trip: the GELU-backward launch, whose largest stream this
+                    // is, ran at 99 TFLOP/s against 130 for the plain product)
+                    f32x4 ex[NPS];
+                    if constexpr (EPI == EPI_BIAS_DROP_RES || EPI == EPI_GELU_BWD) {
+                        const float* src = EPI == EPI_BIAS_DROP_RES ? p.res : p.aux;
+#pragma unroll
+                        for (int ps = 0; ps < NPS; ++ps) {
+                            int64_t grow = m0 + wm * (TMW * 32) + i * 32 + ps * RPS + er;
+                            if constexpr (RAGGED) grow = grow < m_last ? grow : m_last;
+                            ex[ps] = *reinterpret_cast<const f32x4*>(src + grow * p.N + col);
+                        }
+                    }
 #pragma unroll
                     for (int j = 0; j < SW / 32; ++j)
 #pragma unroll
@@ -213,7 +227,7 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt
                             stg[crow(r, hh) * SLD + j * 32 + lq] = acc[i][jc * (SW / 32) + j][r];
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
-#pragma unroll 2
+#pragma unroll
                     for (int ps = 0; ps < NPS; ++ps) {
                         const int rr = ps * RPS + er;
                         const int64_t grow = m0 + wm * (TMW * 32) + i * 32 + rr;
@@ -225,13 +239,13 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt
                             if (epi_th) dk = drop_keep4(p.epi_seed, (uint64_t)(off + (RAGGED ? p.row0 * p.N : 0)), epi_th, epi_sc);
                         }
                         if constexpr (EPI == EPI_BIAS_DROP_RES) {
-                            v = *reinterpret_cast<const f32x4*>(p.res + off) + v * dk;
+                            v = ex[ps] + v * dk;
                         } else if constexpr (EPI == EPI_BIAS_GELU_DROP) {
                             *reinterpret_cast<f32x4*>(p.C2 + off) = v;
                             v.x = gelu_f(v.x) * dk.x; v.y = gelu_f(v.y) * dk.y;
                             v.z = gelu_f(v.z) * dk.z; v.w = gelu_f(v.w) * dk.w;
                         } else if constexpr (EPI == EPI_GELU_BWD) {
-                            const f32x4 h = *reinterpret_cast<const f32x4*>(p.aux + off);
+                            const f32x4 h = ex[ps];
                             v.x *= dk.x * gelu_grad(h.x); v.y *= dk.y * gelu_grad(h.y);
                             v.z *= dk.z * gelu_grad(h.z); v.w *= dk.w * gelu_grad(h.w);
                         }
