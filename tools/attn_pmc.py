@@ -8,7 +8,7 @@ hw = importlib.import_module("sl-hwgat_amd")
 from oracle import hwgat_oracle as O
 HF = hw.functional
 dev = "cuda:0"
-B, F, nW, nH, hd = 64, 128, 5, 2, 64
+B, F, nW, nH, hd = [int(a) for a in sys.argv[1:6]] if len(sys.argv) >= 6 else (64, 128, 5, 2, 64)   # default: config 2, stage 0
 d, K = nH * hd, nW * 16
 g = torch.Generator(device=dev).manual_seed(0)
 qkv = torch.randn(B, F, K, 3 * d, device=dev, generator=g)
