@@ -526,8 +526,11 @@ int launch_tn(TnArgs a, hipStream_t st) {
     // nearly-empty last round), >= 2 rounds, and every slice is >= 16 LDS stages deep.
     auto gcd = [](int x, int y) { while (y) { int t = x % y; x = y; y = t; } return x; };
     const int r_min = n_tiles / gcd(n_tiles, C::SLOTS);
+    // one round where the tiles fill the slots (nearly) evenly -- a second round only doubles the atomic traffic at the
+    // end of the M slices (see hwgat_launch_tn256); HWGAT_TN_ROUNDS=2 restores the round-1 rule for A/B runs
+    static const int min_rounds = [] { const char* e = getenv("HWGAT_TN_ROUNDS"); return e ? atoi(e) : 1; }();
     int r = r_min;
-    while (r < 2) r += r_min;
+    while (r < min_rounds) r += r_min;
     int64_t want = (int64_t)C::SLOTS * r / n_tiles;
     const int64_t max_split = a.M / (TM * 16) > 0 ? a.M / (TM * 16) : 1;
     if (want > max_split) want = max_split;

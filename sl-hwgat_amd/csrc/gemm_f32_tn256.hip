@@ -10,6 +10,7 @@
 //   * the steady-state loop body is branch-free straight-line code whose instruction order is PINNED
 //     with sched_group_barrier: 4 MFMAs, then one LDS read / global load / LDS write, repeated --
 //     never a cluster of memory instructions with a wait, which is what idles a lone wave's MFMA pipe.
+#include <stdlib.h>
 #include <type_traits>
 #include "common.h"
 #include "fused_ops.h"
@@ -184,8 +185,15 @@ int hwgat_launch_tn256(TnArgs a, hipStream_t st) {
     // equal-sized blocks, one resident per CU (256 slots): blocks = n_split * n_tiles an exact multiple of 256
     auto gcd = [](int x, int y) { while (y) { int t = x % y; x = y; y = t; } return x; };
     const int r_min = n_tiles / gcd(n_tiles, 256);
+    // The smallest whole number of rounds that fills every slot with equal blocks -- ONE round when the tile count
+    // divides 256.  Every M slice ends in n_tiles x 256 KB of float atomics (memory-side, ~1.3 TB/s chip-wide); the
+    // round-1 rule (at least two rounds) doubled that traffic for nothing: stage 2 dWproj 112.5 -> 118.6, dW1 124.3 ->
+    // 128.0, dW2 120.0 -> 123.2 TFLOP/s on one box; four rounds 104-119.  The split count has to stay a multiple of 8:
+    // split s lives on XCD s % 8 (its tiles share the M slice through that XCD's L2), and 21 splits x 12 tiles put
+    // 36 blocks on five of the XCDs' 32 CUs -- twice the time (measured).
+    static const int min_rounds = [] { const char* e = getenv("HWGAT_TN_ROUNDS"); return e ? atoi(e) : 1; }();
     int r = r_min;
-    while (r < 2) r += r_min;
+    while (r < min_rounds) r += r_min;
     int64_t want = (int64_t)256 * r / n_tiles;
     const int64_t max_split = a.M / (TM * 16) > 0 ? a.M / (TM * 16) : 1;
     if (want > max_split) want = max_split;
