@@ -73,9 +73,10 @@ __device__ __forceinline__ uint32_t masked_softmax(float (&s)[16], float (&p)[16
 #pragma unroll
         for (int r = 0; r < 16; ++r) { e[r] = sm_exp(s[r] - m0); sum += e[r]; }
         sum += partner(sum);
+        const float cut = thr * sum;                        // e / sum > thr  <=>  e > thr * sum (sum > 0): no 16 divisions
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            if (e[r] / sum > thr) s[r] = 0.f;
+            if (e[r] > cut) s[r] = 0.f;
     }
     uint32_t nz = 0;
     float m = -3.0e38f;
