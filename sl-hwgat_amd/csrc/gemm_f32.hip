@@ -593,15 +593,15 @@ extern "C" int hwgat_linear_nt_f32_ex(const float* A, const float* W, const floa
     //    7-15 % faster when the epilogue is heavy (dropout+residual, GELU, GELU backward): the third
     //    block's MFMAs cover the epilogue's loads/stores.
     // (prologue-carrying launches gain nothing from K16: 570.5 vs 571.1 clips/s)
-    // Large outputs with a deep K loop: the 256x256 one-wave-per-SIMD kernel (gemm_f32_nt256.hip) over the 256-aligned
-    // rows.  Measured on the stage-2 shapes (M = 163 840, same box, tools/nt_lab.py): plain dX 131.5 -> 135.5 and
-    // 129.8 -> 131.6 TFLOP/s, LN-prologue qkv 120.6 -> 124.1, fc1 107.7 -> 111.4, GELU-backward 99.4 -> 103.8,
-    // dropout-prologue dX 110.5 -> 119.1, fc2 (K = 1024) 124.6 -> 129.3; the projection (K = 512 with the
-    // dropout + residual epilogue) is the one launch it loses (114.5 vs 117.4), and at K = 256 it loses everywhere
-    // (exposed epilogue of a lone block per CU).  HWGAT_NT_KERNEL=old keeps everything on the 128x128 kernels.
+    // Outputs whose width is a multiple of 256: the 256x256 one-wave-per-SIMD kernel (gemm_f32_nt256.hip) over the
+    // 256-aligned rows.  Same box, TFLOP/s, 128x128 kernels -> this one (tools/nt_lab.py, profiles/r02b_nt_lab_*.txt):
+    // stage 2 plain dX 131.7 -> 143.2 and 130.4 -> 141.1, LN-prologue qkv 120.6 -> 132.1, fc1 107.8 -> 121.0, fc2 125.9 ->
+    // 136.0, GELU-backward 102.7 -> 114.7, dropout-prologue dX 111.1 -> 124.3, projection 119.1 -> 126.4; stage 1 (K = 256
+    // ... 768) +1 ... +10 %; stage 0 (N = 256, K = 128) +3 ... +5 %.  HWGAT_NT_KERNEL=old keeps everything on the 128x128
+    // kernels, HWGAT_NT256_MINK moves the K threshold (A/B runs).
     static const bool nt_old = [] { const char* e = getenv("HWGAT_NT_KERNEL"); return e && e[0] == 'o'; }();
-    const bool proj_like = epi == EPI_BIAS_DROP_RES && K < 1024;
-    if (!nt_old && !stat && tile_override() == 0 && N % 256 == 0 && K >= 512 && M >= 256 && !proj_like) {
+    static const int nt256_min_k = [] { const char* e = getenv("HWGAT_NT256_MINK"); return e ? atoi(e) : 128; }();
+    if (!nt_old && tile_override() == 0 && N % 256 == 0 && K >= nt256_min_k && M >= 256) {
         const int64_t m256 = M / 256 * 256;
         NtArgs b = a;
         b.M = m256;

@@ -50,7 +50,9 @@ __device__ __forceinline__ void pin() {
     }
 }
 
-template <int PRO, int EPI>
+// STAT (EPI_BIAS_DROP_RES only): row sums / sums of squares of the output for the next LayerNorm and the optional
+// TemporalMerging store, exactly as in gemm_nt_k (see NtArgs in gemm_f32.h)
+template <int PRO, int EPI, bool STAT = false>
 __global__ __launch_bounds__(256, 1) void gemm_nt256_k(NtArgs p) {
     __shared__ __attribute__((aligned(16))) float sm[2 * BUF];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_k(NtArgs p) {
     };
     // staged-slab source pointers: advanced by BK floats per slab, recomputed on a new tile
     const float* pa; const float* pw;
-    auto set_tile = [&](int64_t m0, int n0) {
+    auto set_tile = [&](int64_t m0, int n0) {                   // which tile `issue` reads / whose statistics `commit` applies
         pa = p.A + (m0 + lrow) * p.K + lc4;
         pw = p.W + (int64_t)(n0 + lrow) * p.K + lc4;
         if constexpr (PRO == PRO_LN) {
@@ -147,30 +149,30 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_k(NtArgs p) {
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][e], f.b[j][e], acc[i][j], 0, 0, 0);
     };
-    // one slab: 4 chunks of 64 MFMAs.  NEXT: the slab after this one exists (possibly the next tile's first):
-    // its 16 global loads ride in chunk 0, its LDS commit (with the prologue arithmetic) in chunk 2.
-    auto slab_body = [&](int buf, auto NEXT, int64_t m_next, int s_next) {
-        constexpr bool kNext = decltype(NEXT)::value;
+    // one slab: 4 chunks of 64 MFMAs.  The 16 global loads of the NEXT slab ride in chunk 0, its LDS commit (with the
+    // prologue arithmetic) in chunk 2.  ONE body for every slab: the next slab of a tile's last slab is the next
+    // tile's first (the loaders are retargeted before that body runs; when there is no next tile they harmlessly
+    // re-read this one), so there is no specialised tile-boundary body for the register allocator to spill in
+    // (the round's first version had one, with 50 scratch accesses and an s_waitcnt vmcnt(0) behind every load).
+    auto slab_body = [&](int buf, int64_t m_next, int s_next) {
         fetch(f1, buf, 1);
-        if constexpr (kNext) issue(s_next);
+        issue(s_next);
         mfma64(f0);
-        pin<16, SG_DS_RD, 1, SG_VMEM_RD, kNext ? 1 : 0>();
+        pin<16, SG_DS_RD, 1, SG_VMEM_RD, 1>();
         __builtin_amdgcn_sched_barrier(0);
         fetch(f0, buf, 2);
         mfma64(f1);
         pin<8, SG_DS_RD, 1>();
         __builtin_amdgcn_sched_barrier(0);
         fetch(f1, buf, 3);
-        if constexpr (kNext) commit(buf ^ 1, m_next, s_next);
+        commit(buf ^ 1, m_next, s_next);
         mfma64(f0);
-        pin<8, SG_DS_WR, kNext ? 2 : 0, SG_DS_RD, 1, kNext ? PRO_VALU : 0>();
+        pin<8, SG_DS_WR, 2, SG_DS_RD, 1, PRO_VALU>();
         __builtin_amdgcn_sched_barrier(0);
         mfma64(f1);
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
     };
-    using T = std::true_type;
-    using F = std::false_type;
 
     int t = blockIdx.x;
     if (t >= n_tiles) return;
@@ -190,22 +192,19 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_k(NtArgs p) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-        fetch(f0, buf, 0);
-        for (int s = 0; s + 1 < n_slab; ++s) {                  // steady state: branch-free body
-            slab_body(buf, T{}, m0, s + 1);
-            buf ^= 1;
-            fetch(f0, buf, 0);
-        }
         const int tn = t + gridDim.x;
         int64_t mn = m0; int nn = n0;
-        if (tn < n_tiles) {                                     // last slab: stream the next tile's first slab in
-            tile_origin(tn, mn, nn);
-            set_tile(mn, nn);
-            slab_body(buf, T{}, mn, 0);
-        } else {
-            slab_body(buf, F{}, mn, 0);
+        for (int s = 0; s < n_slab; ++s) {
+            const bool last = s + 1 == n_slab;
+            if (last) {                                         // the slab streamed in next belongs to the next tile
+                if (tn < n_tiles) tile_origin(tn, mn, nn);
+                set_tile(mn, nn);
+            }
+            fetch(f0, buf, 0);
+            slab_body(buf, last ? mn : m0, last ? 0 : s + 1);
+            buf ^= 1;
         }
-        buf ^= 1;                                               // = the next tile's slab 0 (if any); buf^1 is idle now
+        // buf = the next tile's slab 0 (if any); buf^1 is idle now
 
         // ---- epilogue.  acc[i][j]: lane (n = lq, hh), reg r -> C[m = 32 i + crow(r,hh)][n = 32 j + lq] of the wave tile
         {
@@ -213,6 +212,13 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_k(NtArgs p) {
             const float epi_sc = 1.0f / (1.0f - p.epi_p);
             float* stg = sm + (buf ^ 1) * BUF + wave * (32 * SLD);
             const int er = lane >> 5, ec = (lane & 31) * 4;     // pass ps covers rows 2 ps + er, floats ec..ec+3
+            float* rowstat = sm + (buf ^ 1) * BUF + 4 * (32 * SLD);               // [256][2] behind the staging strips
+            if constexpr (STAT) {
+                static_assert(4 * 32 * SLD + 2 * BT <= BUF, "no room for the row statistics");
+                rowstat[tid] = 0.f;
+                rowstat[tid + 256] = 0.f;
+                __syncthreads();
+            }
             const int col = n0 + wn * 128 + ec;
             f32x4 bv = {0.f, 0.f, 0.f, 0.f};
             if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_DROP_RES || EPI == EPI_BIAS_GELU_DROP)
@@ -253,10 +259,28 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_k(NtArgs p) {
                         v.x *= dk.x * gelu_grad(h.x); v.y *= dk.y * gelu_grad(h.y);
                         v.z *= dk.z * gelu_grad(h.z); v.w *= dk.w * gelu_grad(h.w);
                     }
-                    *reinterpret_cast<f32x4*>(p.C + off) = v;
+                    if constexpr (STAT) {
+                        float s1 = (v.x + v.y) + (v.z + v.w), s2 = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+#pragma unroll
+                        for (int o = 16; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+                        const int lr = wm * 128 + i * 32 + 2 * ps + er;
+                        if ((lane & 31) == 0) { atomicAdd(rowstat + 2 * lr, s1); atomicAdd(rowstat + 2 * lr + 1, s2); }
+                        int64_t doff = off;
+                        if (p.mg_K > 0) { int64_t mr; merge_row(m0 + lr, p.mg_F, p.mg_K, p.N, mr, doff); doff += col; }
+                        *reinterpret_cast<f32x4*>(p.C + doff) = v;
+                    } else {
+                        *reinterpret_cast<f32x4*>(p.C + off) = v;
+                    }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
+            }
+            if constexpr (STAT) {
+                __syncthreads();
+                int64_t mr = m0 + tid, doff;                    // 256 consecutive rows -> coalesced global atomics
+                if (p.mg_K > 0) merge_row(m0 + tid, p.mg_F, p.mg_K, p.N, mr, doff);
+                atomicAdd(p.stat_sum + mr, rowstat[2 * tid]);
+                atomicAdd(p.stat_sq + mr, rowstat[2 * tid + 1]);
             }
         }
         __syncthreads();            // staging lives in buf^1, which the next tile's second slab overwrites
@@ -268,6 +292,13 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_k(NtArgs p) {
 
 template <int PRO>
 int launch(const NtArgs& a, int epi, int grid, hipStream_t st) {
+    if (a.stat_sum != nullptr) {                                // validated by the caller: PRO_NONE, EPI_BIAS_DROP_RES
+        if constexpr (PRO == PRO_NONE) {
+            gemm_nt256_k<PRO_NONE, EPI_BIAS_DROP_RES, true><<<grid, 256, 0, st>>>(a);
+            HWGAT_LAUNCH_CHECK();
+        }
+        return HWGAT_EINVAL;
+    }
     switch (epi) {
         case EPI_BIAS: gemm_nt256_k<PRO, EPI_BIAS><<<grid, 256, 0, st>>>(a); break;
         case EPI_BIAS_DROP_RES: gemm_nt256_k<PRO, EPI_BIAS_DROP_RES><<<grid, 256, 0, st>>>(a); break;
