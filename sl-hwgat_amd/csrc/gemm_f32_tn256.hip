@@ -5,8 +5,10 @@
 // Structure (what the vendor's best fp32 kernel does, per its disassembly -- DESIGN.md section 5):
 //   * 256x256 dW tile per block, 4 waves x (128x128) = 4x4 v_mfma_f32_32x32x2_f32 tiles, the 256
 //     accumulator registers live in AGPRs, ONE wave per SIMD;
-//   * 16-row stages of both operands in a 3-deep LDS ring; the stage two ahead is loaded to registers
-//     at the top of an iteration and committed in the second half; one barrier per 128 MFMAs;
+//   * 16-row stages of both operands in a 3-deep LDS ring; the global loads of the stage THREE ahead are issued at
+//     the top of an iteration into one of two register sets and committed to the ring in the second half of the
+//     NEXT iteration (12 000 matrix-pipe cycles of lead; with one register set and 4 000 cycles the commit waited
+//     on HBM: round 2); one barrier per 128 MFMAs;
 //   * the steady-state loop body is branch-free straight-line code whose instruction order is PINNED
 //     with sched_group_barrier: 4 MFMAs, then one LDS read / global load / LDS write, repeated --
 //     never a cluster of memory instructions with a wait, which is what idles a lone wave's MFMA pipe.
@@ -55,34 +57,36 @@ __global__ __launch_bounds__(256, 1) void gemm_tn256_k(TnArgs p) {
     const int lrow = tid >> 6, lc4 = (tid & 63) * 4;            // rows lrow + 4*i (i < 4), floats lc4..lc4+3
     const uint32_t pro_th = drop_thresh(p.pro_p);
     const float pro_sc = 1.0f / (1.0f - p.pro_p);
-    f32x4 ra[4], rb[4];
-    float bm[4], bs[4];
+    f32x4 ra[2][4], rb[2][4];                                   // two staging register sets (stage k uses set k & 1)
+    float bm[2][4], bs[2][4];
     f32x4 colsum = {0.f, 0.f, 0.f, 0.f};
     f32x4 lg = {1.f, 1.f, 1.f, 1.f}, lb = {0.f, 0.f, 0.f, 0.f};
     if constexpr (BLN) {
         lg = *reinterpret_cast<const f32x4*>(p.gamma + k0 + lc4);
         lb = *reinterpret_cast<const f32x4*>(p.beta + k0 + lc4);
     }
-    auto issue = [&](int it) {
+    auto issue = [&](auto QC, int it) {
+        constexpr int Q = decltype(QC)::value;
         const int64_t r0 = r_begin + (int64_t)it * TM + lrow;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            ra[i] = *reinterpret_cast<const f32x4*>(p.A + (r0 + 4 * i) * p.N + n0 + lc4);
-            rb[i] = *reinterpret_cast<const f32x4*>(p.B + (r0 + 4 * i) * p.K + k0 + lc4);
-            if constexpr (BLN) { bm[i] = p.mean[r0 + 4 * i]; bs[i] = p.rstd[r0 + 4 * i]; }
+            ra[Q][i] = *reinterpret_cast<const f32x4*>(p.A + (r0 + 4 * i) * p.N + n0 + lc4);
+            rb[Q][i] = *reinterpret_cast<const f32x4*>(p.B + (r0 + 4 * i) * p.K + k0 + lc4);
+            if constexpr (BLN) { bm[Q][i] = p.mean[r0 + 4 * i]; bs[Q][i] = p.rstd[r0 + 4 * i]; }
         }
     };
-    auto commit = [&](int stage, int it) {
+    auto commit = [&](auto QC, int stage, int it, float live) {
+        constexpr int Q = decltype(QC)::value;
         float* As = sm + stage * STG;
         float* Bs = As + TM * BT;
         const int64_t r0 = r_begin + (int64_t)it * TM + lrow;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            f32x4 a = ra[i], b = rb[i];
+            f32x4 a = ra[Q][i], b = rb[Q][i];
             if constexpr (PRO == PRO_DROP)
                 a *= drop_keep4(p.pro_seed, (uint64_t)(r0 + 4 * i) * p.N + n0 + lc4, pro_th, pro_sc);
-            if constexpr (BLN) b = (b - bm[i]) * bs[i] * lg + lb;
-            colsum += a;
+            if constexpr (BLN) b = (b - bm[Q][i]) * bs[Q][i] * lg + lb;
+            colsum += a * live;
             *reinterpret_cast<f32x4*>(As + (lrow + 4 * i) * BT + lc4) = a;
             *reinterpret_cast<f32x4*>(Bs + (lrow + 4 * i) * BT + lc4) = b;
         }
@@ -117,16 +121,21 @@ __global__ __launch_bounds__(256, 1) void gemm_tn256_k(TnArgs p) {
                 for (int jj = 0; jj < 4; ++jj)
                     acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(c.a[e][i], c.b[e][jj], acc[i][jj], 0, 0, 0);
     };
-    // one stage: 4 chunks x 32 MFMAs.  LOAD: stream stage it+2 in (8 global loads in chunk 0, 8 LDS writes in
-    // chunk 2).  NEXT: prefetch the first chunk of stage it+1 during chunk 3.
+    // one stage (iteration `it`, parity PAR = it & 1): 4 chunks x 32 MFMAs.
+    //   the global loads of stage it+3 go out in chunk 0, into register set PAR^1;
+    //   stage it+2 (requested a whole iteration ago, register set PAR) is written to its ring slot in chunk 2;
+    //   the first operand chunk of stage it+1 is prefetched during chunk 3.
+    // ONE body per parity for every stage: past the end of the M slice the loaders re-read the last stage and the
+    // commit lands in a ring slot nobody reads any more (its column-sum contribution is multiplied by zero), so there
+    // are no specialised tail bodies -- with ten of them the register allocator spilled 2 000+ registers.
     Chunk c0, c1;
-    auto stage_body = [&](int it, auto LOAD, auto NEXT) {
-        constexpr bool kLoad = decltype(LOAD)::value, kNext = decltype(NEXT)::value;
+    auto stage_body = [&](auto PARC, int it) {
+        constexpr int PAR = decltype(PARC)::value;
         const int st = it % NST;
-        if constexpr (kLoad) issue(it + 2);
+        issue(std::integral_constant<int, PAR ^ 1>{}, it + 3 < n_it ? it + 3 : n_it - 1);
         fetch(c1, st, 1);
         mfma_chunk(c0);
-        il8<SG_DS_RD, 2, SG_VMEM_RD, kLoad ? 1 : 0>();
+        il8<SG_DS_RD, 2, SG_VMEM_RD, 1>();
         __builtin_amdgcn_sched_barrier(0);
         fetch(c0, st, 2);
         mfma_chunk(c1);
@@ -134,28 +143,30 @@ __global__ __launch_bounds__(256, 1) void gemm_tn256_k(TnArgs p) {
         __builtin_amdgcn_sched_barrier(0);
         fetch(c1, st, 3);
         mfma_chunk(c0);
-        if constexpr (kLoad) commit((it + 2) % NST, it + 2);
-        il8<SG_DS_RD, 2, SG_DS_WR, kLoad ? 1 : 0>();
+        commit(std::integral_constant<int, PAR>{}, (it + 2) % NST, it + 2 < n_it ? it + 2 : n_it - 1, it + 2 < n_it ? 1.0f : 0.0f);
+        il8<SG_DS_RD, 2, SG_DS_WR, 1>();
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (kNext) fetch(c0, (it + 1) % NST, 0);
+        fetch(c0, (it + 1) % NST, 0);
         mfma_chunk(c1);
-        il8<SG_DS_RD, kNext ? 2 : 0, 0, 0>();
+        il8<SG_DS_RD, 2, 0, 0>();
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
     };
-    using T = std::true_type;
-    using F = std::false_type;
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
 
-    // prologue: stages 0 and 1
-    issue(0);
-    commit(0, 0);
-    if (n_it > 1) { issue(1); commit(1, 1); }
+    // prologue: stages 0 and 1 into the ring, stage 2 in flight (register set 0).  n_it is even and >= 2.
+    issue(P0{}, 0);
+    commit(P0{}, 0, 0, 1.0f);
+    issue(P1{}, 1);
+    commit(P1{}, 1, 1, 1.0f);
+    issue(P0{}, 2 < n_it ? 2 : n_it - 1);
     __syncthreads();
     fetch(c0, 0, 0);
-    int it = 0;
-    for (; it + 2 < n_it; ++it) stage_body(it, T{}, T{});        // steady state: branch-free body
-    if (it + 1 < n_it) { stage_body(it, F{}, T{}); ++it; }
-    stage_body(it, F{}, F{});
+    for (int it = 0; it < n_it; it += 2) {
+        stage_body(P0{}, it);
+        stage_body(P1{}, it + 1);
+    }
 
     // D[i = n][j = k]: lane (k = lq, hh), reg r -> dW[n = crow(r,hh)][k]
 #pragma unroll
@@ -180,7 +191,7 @@ __global__ __launch_bounds__(256, 1) void gemm_tn256_k(TnArgs p) {
 }  // namespace
 
 int hwgat_launch_tn256(TnArgs a, hipStream_t st) {
-    if (a.N % BT || a.K % BT || a.M % TM) return HWGAT_ESHAPE;
+    if (a.N % BT || a.K % BT || a.M % (2 * TM)) return HWGAT_ESHAPE;     // an even number of 16-row stages per M slice
     const int n_tiles = (a.N / BT) * (a.K / BT);
     // equal-sized blocks, one resident per CU (256 slots): blocks = n_split * n_tiles an exact multiple of 256
     auto gcd = [](int x, int y) { while (y) { int t = x % y; x = y; y = t; } return x; };
@@ -199,7 +210,7 @@ int hwgat_launch_tn256(TnArgs a, hipStream_t st) {
     if (want > max_split) want = max_split;
     if (want < 1) want = 1;
     int64_t rows = (a.M + want - 1) / want;
-    rows = (rows + TM - 1) / TM * TM;
+    rows = (rows + 2 * TM - 1) / (2 * TM) * (2 * TM);
     a.n_split = (int)((a.M + rows - 1) / rows);
     a.rows_per_split = rows;
     const int grid = ((a.n_split + 7) / 8) * 8 * n_tiles;
