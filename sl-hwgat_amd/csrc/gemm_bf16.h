@@ -1,0 +1,32 @@
+// argument block of the bf16 NT linear kernels (gemm_bf16.hip, gemm_bf16_nt256.hip)
+#pragma once
+#include "common.h"
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+struct NtArgsB {
+    const bf16_t* A; const bf16_t* W; const float* bias; bf16_t* C;
+    bf16_t* C2; const bf16_t* res; const bf16_t* aux;
+    const float* mean; const float* rstd; const float* gamma; const float* beta;
+    int64_t M; int N, K;
+    uint32_t pro_seed, epi_seed; float pro_p, epi_p;
+    int64_t row0;          // RAGGED tail launches: global index of this launch's first row (dropout hash)
+};
+
+__device__ __forceinline__ void unpack8(u32x4 r, float (&v)[8]) {
+    v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+    v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+    v[4] = __uint_as_float(r.z << 16); v[5] = __uint_as_float(r.z & 0xffff0000u);
+    v[6] = __uint_as_float(r.w << 16); v[7] = __uint_as_float(r.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+    bf16x2 t = {(bf16_t)a, (bf16_t)b};
+    return *reinterpret_cast<uint32_t*>(&t);
+}
+__device__ __forceinline__ u32x4 pack8(const float (&v)[8]) {
+    u32x4 r = {pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
+    return r;
+}
+
+// 256x256 C tile, 4 waves x (128x128), one wave per SIMD (gemm_bf16_nt256.hip); needs M % 256 == N % 256 == K % 64 == 0
+int hwgat_launch_nt256_bf16(const NtArgsB& a, int pro, int epi, hipStream_t st);

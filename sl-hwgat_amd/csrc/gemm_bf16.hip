@@ -14,37 +14,14 @@
 //                  read of the row-major tile: ds_read_b64_tr_b16 (gfx950 hardware transpose)
 //                  on LDS rows padded to 320 bytes (4 rows of a 4x16 block land in disjoint
 //                  bank quarters -> conflict-free).
+#include <stdlib.h>
 #include "common.h"
 #include "fused_ops.h"
+#include "gemm_bf16.h"
 
 namespace {
 
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
-
-__device__ __forceinline__ void unpack8(u32x4 r, float (&v)[8]) {
-    v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
-    v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
-    v[4] = __uint_as_float(r.z << 16); v[5] = __uint_as_float(r.z & 0xffff0000u);
-    v[6] = __uint_as_float(r.w << 16); v[7] = __uint_as_float(r.w & 0xffff0000u);
-}
-__device__ __forceinline__ uint32_t pack2(float a, float b) {
-    bf16x2 t = {(bf16_t)a, (bf16_t)b};
-    return *reinterpret_cast<uint32_t*>(&t);
-}
-__device__ __forceinline__ u32x4 pack8(const float (&v)[8]) {
-    u32x4 r = {pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7])};
-    return r;
-}
-
-struct NtArgsB {
-    const bf16_t* A; const bf16_t* W; const float* bias; bf16_t* C;
-    bf16_t* C2; const bf16_t* res; const bf16_t* aux;
-    const float* mean; const float* rstd; const float* gamma; const float* beta;
-    int64_t M; int N, K;
-    uint32_t pro_seed, epi_seed; float pro_p, epi_p;
-    int64_t row0;          // RAGGED tail launches: global index of this launch's first row (dropout hash)
-};
 
 // 128x128 tile, 4 waves, K slabs of 64 (144-byte LDS rows), 72 KB -> 2 blocks / CU.
 // Measured alternatives (all slower or neutral on MI355X, config 3; NT time per step):
@@ -496,6 +473,7 @@ extern "C" int hwgat_linear_nt_bf16(const void* A, const void* W, const float* b
     if (epi == EPI_BIAS_GELU_DROP && !C2) return HWGAT_EINVAL;
     if (epi == EPI_GELU_BWD && !aux) return HWGAT_EINVAL;
     if (pro_p < 0.f || pro_p >= 1.f || epi_p < 0.f || epi_p >= 1.f) return HWGAT_EINVAL;
+    if (pro == PRO_DROP && pro_p == 0.f) pro = PRO_NONE;          // eval mode: no mask to hash
     NtArgsB a{(const bf16_t*)A, (const bf16_t*)W, bias, (bf16_t*)C, (bf16_t*)C2, (const bf16_t*)res,
               (const bf16_t*)aux, mean, rstd, gamma, beta, M, N, K, pro_seed, epi_seed, pro_p, epi_p, 0};
     hipStream_t st = (hipStream_t)stream;
@@ -507,6 +485,24 @@ extern "C" int hwgat_linear_nt_bf16(const void* A, const void* W, const float* b
             if (rc) return rc;
         }
         const NtArgsB t = nt_rows_b(a, m_bulk, M - m_bulk);
+        switch (pro) {
+            case PRO_NONE: return launch_nt_b<PRO_NONE, NtB64, true>(t, epi, st);
+            case PRO_LN: return launch_nt_b<PRO_LN, NtB64, true>(t, epi, st);
+            case PRO_DROP: return launch_nt_b<PRO_DROP, NtB64, true>(t, epi, st);
+            default: return HWGAT_EINVAL;
+        }
+    }
+    // outputs whose width is a multiple of 256: the 256x256 one-wave-per-SIMD kernel (gemm_bf16_nt256.hip: half the
+    // L2 -> LDS stream of the 128x128 tile) over the 256-aligned rows; HWGAT_NT_KERNEL=old keeps the 128x128 kernel
+    static const bool nt_old = [] { const char* e = getenv("HWGAT_NT_KERNEL"); return e && e[0] == 'o'; }();
+    static const int nt256_min_k = [] { const char* e = getenv("HWGAT_NT256_MINK"); return e ? atoi(e) : 128; }();
+    if (!nt_old && N % 256 == 0 && K >= nt256_min_k && M >= 256) {
+        const int64_t m256 = M / 256 * 256;
+        NtArgsB b = a;
+        b.M = m256;
+        const int rc = hwgat_launch_nt256_bf16(b, pro, epi, st);
+        if (rc || m256 == M) return rc;
+        const NtArgsB t = nt_rows_b(a, m256, M - m256);   // 128 rows left: RAGGED instantiation (global row index in the dropout hash)
         switch (pro) {
             case PRO_NONE: return launch_nt_b<PRO_NONE, NtB64, true>(t, epi, st);
             case PRO_LN: return launch_nt_b<PRO_LN, NtB64, true>(t, epi, st);

@@ -358,3 +358,63 @@ def test_nt_epilogue_row_statistics_and_merged_store(M, N, K, F, Kt):
     wd = want.double().view(-1, 2 * N)
     assert rel_err(mean2.cpu(), wd.mean(-1).cpu()) < 1e-5
     assert rel_err(rstd2.cpu(), (wd.var(-1, unbiased=False) + 1e-5).rsqrt().cpu()) < 1e-5
+
+
+@pytest.mark.parametrize("pro,epi", _LOOP_CASES)
+@pytest.mark.parametrize("M,N,K", [(256 * 301, 512, 512), (256 * 150 + 128, 256, 128)])
+def test_bf16_nt256_persistent_tile_loop_every_prologue_and_epilogue(M, N, K, pro, epi):
+    """gemm_nt256_bf16_k (N % 256 == 0): more tiles than its 256 resident blocks, odd row-block count, a 128-row
+    remainder launch; every prologue / epilogue pair against fp64 on sampled row blocks (operands and the prologue's
+    output rounded to bf16 like the kernel's MFMA operands)."""
+    p = 0.1
+    g = torch.Generator(device=DEV).manual_seed(M + N + len(pro) * 7 + len(epi))
+    A = torch.randn(M, K, device=DEV, generator=g).bfloat16()
+    W = (torch.randn(N, K, device=DEV, generator=g) * 0.1).bfloat16()
+    b = torch.randn(N, device=DEV, generator=g)
+    res = torch.randn(M, N, device=DEV, generator=g).bfloat16()
+    aux = torch.randn(M, N, device=DEV, generator=g).bfloat16()
+    gamma, beta = torch.randn(K, device=DEV, generator=g), torch.randn(K, device=DEV, generator=g)
+    kw = {}
+    if pro == "ln":
+        mean, rstd = HF.ln_stats(A, gamma, beta)
+        kw.update(pro=HF.PRO_LN, ln=(mean, rstd, gamma, beta))
+    elif pro == "drop":
+        kw.update(pro=HF.PRO_DROP, pro_seed=77, pro_p=p)
+    code = {"none": HF.EPI_NONE, "bias": HF.EPI_BIAS, "drop_res": HF.EPI_BIAS_DROP_RES,
+            "gelu_drop": HF.EPI_BIAS_GELU_DROP, "gelu_bwd": HF.EPI_GELU_BWD}[epi]
+    bias = None if epi in ("none", "gelu_bwd") else b
+    if epi in ("drop_res", "gelu_drop", "gelu_bwd"):
+        kw.update(epi_seed=1234, epi_p=p)
+    got = HF.linear_nt(A, W, bias, epi=code, res=res if epi == "drop_res" else None,
+                       aux=aux if epi == "gelu_bwd" else None, **kw)
+    got2 = None
+    if epi == "gelu_drop":
+        got, got2 = got
+    nb = M // 128
+    blocks = sorted({0, 1, 2, 15, 16, nb // 2, nb - 5, nb - 2, nb - 1, 511, 512, 513})
+    rows = torch.cat([torch.arange(128) + 128 * bi for bi in blocks if 0 <= bi < nb]).to(DEV)
+    Ar = A[rows].double().cpu()
+    if pro == "ln":
+        Ar = torch.nn.functional.layer_norm(Ar, (K,), gamma.double().cpu(), beta.double().cpu())
+    elif pro == "drop":
+        Ar = Ar * HF.dropout_mask((M, K), 77, p, DEV)[rows].double().cpu()
+    Ar = Ar.float().bfloat16().double()                     # the MFMA operand is bf16
+    lin = Ar @ W.double().cpu().t()
+    if bias is not None:
+        lin = lin + b.double().cpu()
+    mask = HF.dropout_mask((M, N), 1234, p, DEV)[rows].double().cpu() if "epi_p" in kw else None
+    if epi == "drop_res":
+        ref = res[rows].double().cpu() + lin * mask
+    elif epi == "gelu_drop":
+        assert rel_err(got2[rows].float().cpu(), lin) < BT
+        ref = torch.nn.functional.gelu(got2[rows].double().cpu()) * mask
+    elif epi == "gelu_bwd":
+        h = aux[rows].double().cpu().requires_grad_(True)
+        torch.nn.functional.gelu(h).sum().backward()
+        ref = lin * mask * h.grad
+    else:
+        ref = lin
+    assert rel_err(got[rows].float().cpu(), ref) < BT
+    worst = max(rel_err(got[rows][i * 128:(i + 1) * 128].float().cpu(), ref[i * 128:(i + 1) * 128]) for i in range(len(rows) // 128))
+    assert worst < 2 * BT, worst
+    assert bool(torch.isfinite(got.float()).all())
