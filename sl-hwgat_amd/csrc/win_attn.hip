@@ -127,16 +127,23 @@ __global__ __launch_bounds__(256, 2) void win_attn_fwd_k(const T* __restrict__ q
     if (u >= n_units) return;
 
     u32x4 qr[NLD], kr[NLD];
-    auto issue_qk = [&](const Unit& un) {
+    float vn[16][NT];                  // V of the NEXT unit, already in the MFMA B-operand layout
+    // the whole next unit is requested while this one computes: Q and K as 16-byte row chunks for the LDS tiles, V
+    // straight into operand registers.  (V used to be requested at the top of its own unit and was needed ~2 700
+    // cycles later -- less than an HBM round trip under load, so every unit stalled on it.)
+    auto issue_qkv = [&](const Unit& un) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const T* p = qkv + tok_of(un, i * RPI + crow_l) * row3d + un.head * HD + ccol;
             qr[i] = *reinterpret_cast<const u32x4*>(p);
             kr[i] = *reinterpret_cast<const u32x4*>(p + g.d);
         }
+        const T* vb = qkv + 2 * g.d + un.head * HD + lq * NT;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) load_nt<T, NT>(vb + tok_of(un, crow(r, hh)) * row3d, vn[r]);
     };
     Unit cur = decode_unit(g, u);
-    issue_qk(cur);
+    issue_qkv(cur);
 
     for (; u < n_units; u += nwaves) {
         // -- stage Q (pre-scaled, HWGATE.py:89) and K into the wave's LDS tiles
@@ -146,18 +153,17 @@ __global__ __launch_bounds__(256, 2) void win_attn_fwd_k(const T* __restrict__ q
             chunk<T>::to_lds(dq, qr[i], qk_scale<HD>());
             chunk<T>::to_lds(dq + 32 * LDW, kr[i], 1.0f);
         }
-        // -- V of this unit straight into the MFMA B-operand layout
+        // -- V of this unit arrived with the previous prefetch
         float v[16][NT];
-        {
-            const T* vb = qkv + 2 * g.d + cur.head * HD + lq * NT;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) load_nt<T, NT>(vb + tok_of(cur, crow(r, hh)) * row3d, v[r]);
-        }
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) v[r][nt] = vn[r][nt];
         const uint32_t mbits = maskbits[cur.mrow + lq];
-        // -- prefetch next unit's q,k while this one computes
+        // -- prefetch the next unit's q, k, v while this one computes
         const int un = u + nwaves;
         Unit nxt = cur;
-        if (un < n_units) { nxt = decode_unit(g, un); issue_qk(nxt); }
+        if (un < n_units) { nxt = decode_unit(g, un); issue_qkv(nxt); }
         lds_fence();
 
         f32x16 st = tile_xyT<HD, LDW>(Ks, Qs, lq, hh);     // st[r] = S[q=lq][key=crow(r,hh)]
