@@ -211,6 +211,13 @@ int hwgat_linear_nt_bf16(const void* A, const void* W, const float* bias, void* 
                          int pro, const float* mean, const float* rstd, const float* gamma,
                          const float* beta, uint32_t pro_seed, float pro_p, int epi, const void* res,
                          void* C2, const void* aux, uint32_t epi_seed, float epi_p, void* stream);
+/* hwgat_linear_nt_f32_ex for bf16 activations: the statistics are those of the bf16-rounded output values (what the
+ * next LayerNorm reads), the merged store writes bf16. */
+int hwgat_linear_nt_bf16_ex(const void* A, const void* W, const float* bias, void* C, int64_t M, int N, int K,
+                            int pro, const float* mean, const float* rstd, const float* gamma,
+                            const float* beta, uint32_t pro_seed, float pro_p, int epi, const void* res,
+                            void* C2, const void* aux, uint32_t epi_seed, float epi_p, float* stat_sum,
+                            float* stat_sq, int merge_F, int merge_K, void* stream);
 int hwgat_linear_tn_bf16(const void* A, const void* B, float* dW, float* db, int64_t M, int N, int K,
                          uint32_t pro_seed, float pro_p, const float* mean, const float* rstd,
                          const float* gamma, const float* beta, void* stream);

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "../../include/hwgat_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -52,6 +53,21 @@ template <> struct io<bf16_t> {
     __device__ static __forceinline__ float ld(const bf16_t* p) { return (float)*p; }
     __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = (bf16_t)v; }
 };
+
+// Sum over aligned groups of W lanes (W = 8, 16 or 32) with DPP modifiers on plain vector adds -- no LDS crossbar
+// (`__shfl_xor` is a ds_bpermute: an LDS round trip per step, ruinous in an exposed epilogue).  A DPP "row" is 16 lanes.
+template <int W>
+__device__ __forceinline__ float group_sum(float v) {
+    auto dpp = [](float x, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true));
+    };
+    v += dpp(v, std::integral_constant<int, 0xB1>{});            // quad_perm [1,0,3,2]
+    v += dpp(v, std::integral_constant<int, 0x4E>{});            // quad_perm [2,3,0,1]
+    v += dpp(v, std::integral_constant<int, 0x141>{});           // row_half_mirror: lanes 0-7 / 8-15 of a row reversed
+    if constexpr (W >= 16) v += dpp(v, std::integral_constant<int, 0x140>{});   // row_mirror
+    if constexpr (W >= 32) v += __shfl_xor(v, 16, 64);
+    return v;
+}
 
 // butterfly all-reduce over the low `W` lanes-groups (W = 32 or 64)
 template <int W>

@@ -11,6 +11,35 @@ struct NtArgsB {
     int64_t M; int N, K;
     uint32_t pro_seed, epi_seed; float pro_p, epi_p;
     int64_t row0;          // RAGGED tail launches: global index of this launch's first row (dropout hash)
+    // EPI_BIAS_DROP_RES only: row sums / sums of squares of the (bf16-rounded) output and the TemporalMerging store,
+    // exactly as NtArgs in gemm_f32.h
+    float* stat_sum; float* stat_sq;
+    int mg_F, mg_K;
+};
+
+// output row m -> row of the merged (B, F/2, K, 2N) tensor for a lane that walks rows m, m + step, ... of one tile:
+// ONE pair of 32-bit divisions, then carries (see MergeWalk in gemm_f32.h)
+struct MergeWalk {
+    int k, f; int64_t b; int F, K, step;
+    __device__ __forceinline__ void start(int64_t m, int F_, int K_, int step_) {
+        F = F_; K = K_; step = step_;
+        const uint32_t mm = (uint32_t)m, fr = mm / (uint32_t)K_;
+        k = (int)(mm - fr * (uint32_t)K_);
+        const uint32_t bb = fr / (uint32_t)F_;
+        f = (int)(fr - bb * (uint32_t)F_);
+        b = bb;
+    }
+    __device__ __forceinline__ int64_t mrow() const { return (b * (F >> 1) + (f >> 1)) * K + k; }
+    __device__ __forceinline__ int64_t off(int N) const { return mrow() * (2 * (int64_t)N) + (int64_t)(f & 1) * N; }
+    __device__ __forceinline__ void next() {
+        k += step;
+        const bool wk = k >= K;
+        k -= wk ? K : 0;
+        f += wk ? 1 : 0;
+        const bool wf = f >= F;
+        f -= wf ? F : 0;
+        b += wf ? 1 : 0;
+    }
 };
 
 __device__ __forceinline__ void unpack8(u32x4 r, float (&v)[8]) {

@@ -38,7 +38,7 @@ struct SlabIt {
 
 // RAGGED: launch over the last M % 128 rows of a token count that is not a multiple of the tile (see the fp32
 // family, gemm_f32.hip): clamped loads, guarded stores, dropout hashed with the global row index.
-template <int PRO, int EPI, typename C, bool RAGGED = false>
+template <int PRO, int EPI, typename C, bool RAGGED = false, int STAT = 0>      // STAT: see gemm_nt256_bf16_k
 __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt_bf16_k(NtArgsB p) {
     constexpr int BM = C::BM, BN = C::BN, BK = C::BK, LDT = C::LDT, PA = C::PA, PW = C::PW, RPP = C::RPP;
     constexpr int TMW = C::TMW, TNW = C::TNW;
@@ -168,6 +168,12 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt
         constexpr int SLD = SW + 4, LPR = SW / 8, RPS = 64 / LPR, NPS = 32 / RPS;
         float* stg = reinterpret_cast<float*>(sm + idle * ((BM + BN) * LDT)) + wave * (32 * SLD);
         const int er = lane / LPR, ec = (lane % LPR) * 8;
+        float* rowstat = reinterpret_cast<float*>(sm + idle * ((BM + BN) * LDT)) + (C::THREADS / 64) * (32 * SLD);   // [BM][2]
+        if constexpr (STAT != 0) {
+            static_assert(((C::THREADS / 64) * 32 * SLD + 2 * BM) * 4 <= (BM + BN) * LDT * 2, "no room for the row statistics");
+            for (int q = tid; q < 2 * BM; q += C::THREADS) rowstat[q] = 0.f;
+            __syncthreads();
+        }
 #pragma unroll
         for (int jc = 0; jc < TNW * 32 / SW; ++jc) {
             const int col = n0 + wn * (TNW * 32) + jc * SW + ec;
@@ -176,6 +182,8 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt
                 if (p.bias) { bv0 = *reinterpret_cast<const f32x4*>(p.bias + col); bv1 = *reinterpret_cast<const f32x4*>(p.bias + col + 4); }
 #pragma unroll
             for (int i = 0; i < TMW; ++i) {
+                MergeWalk mw;
+                if constexpr (STAT == 2) mw.start(m0 + wm * (TMW * 32) + i * 32 + er, p.mg_F, p.mg_K, RPS);
                 u32x4 ex[NPS];
                 if constexpr (EPI == EPI_BIAS_DROP_RES || EPI == EPI_GELU_BWD) {
                     const bf16_t* src = EPI == EPI_BIAS_DROP_RES ? p.res : p.aux;
@@ -228,10 +236,37 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt
 #pragma unroll
                         for (int e = 0; e < 8; ++e) o8[e] = o8[e] * dk[e] * gelu_grad(h[e]);
                     }
-                    *reinterpret_cast<u32x4*>(p.C + off) = pack8(o8);
+                    const u32x4 outv = pack8(o8);
+                    if constexpr (STAT != 0) {                  // statistics of the bf16 values the next LayerNorm reads
+                        float q[8];
+                        unpack8(outv, q);
+                        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { s1 += q[e]; s2 += q[e] * q[e]; }
+                        s1 = group_sum<LPR>(s1); s2 = group_sum<LPR>(s2);
+                        const int lr = wm * (TMW * 32) + i * 32 + rr;
+                        if ((lane % LPR) == 0) { atomicAdd(rowstat + 2 * lr, s1); atomicAdd(rowstat + 2 * lr + 1, s2); }
+                        if constexpr (STAT == 2) {
+                            *reinterpret_cast<u32x4*>(p.C + mw.off(p.N) + col) = outv;
+                            mw.next();
+                        } else {
+                            *reinterpret_cast<u32x4*>(p.C + off) = outv;
+                        }
+                    } else {
+                        *reinterpret_cast<u32x4*>(p.C + off) = outv;
+                    }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if constexpr (STAT != 0) {
+            __syncthreads();
+            for (int q = tid; q < BM; q += C::THREADS) {
+                int64_t mr = m0 + q;
+                if constexpr (STAT == 2) { MergeWalk w; w.start(m0 + q, p.mg_F, p.mg_K, 1); mr = w.mrow(); }
+                atomicAdd(p.stat_sum + mr, rowstat[2 * q]);
+                atomicAdd(p.stat_sq + mr, rowstat[2 * q + 1]);
             }
         }
     };
@@ -436,6 +471,14 @@ template <int PRO, typename C, bool RAGGED = false>
 int launch_nt_b(const NtArgsB& a, int epi, hipStream_t st) {
     const int64_t tiles = ((a.M + C::BM - 1) / C::BM) * (a.N / C::BN);
     const int grid = (int)(tiles < C::SLOTS ? tiles : C::SLOTS);
+    if (a.stat_sum != nullptr) {                                // validated by the caller: PRO_NONE, EPI_BIAS_DROP_RES, whole tiles
+        if constexpr (PRO == PRO_NONE && !RAGGED) {
+            if (a.mg_K > 0) gemm_nt_bf16_k<PRO_NONE, EPI_BIAS_DROP_RES, C, false, 2><<<grid, C::THREADS, 0, st>>>(a);
+            else gemm_nt_bf16_k<PRO_NONE, EPI_BIAS_DROP_RES, C, false, 1><<<grid, C::THREADS, 0, st>>>(a);
+            HWGAT_LAUNCH_CHECK();
+        }
+        return HWGAT_EINVAL;
+    }
     switch (epi) {
         case EPI_BIAS: gemm_nt_bf16_k<PRO, EPI_BIAS, C, RAGGED><<<grid, C::THREADS, 0, st>>>(a); break;
         case EPI_BIAS_DROP_RES: gemm_nt_bf16_k<PRO, EPI_BIAS_DROP_RES, C, RAGGED><<<grid, C::THREADS, 0, st>>>(a); break;
@@ -462,10 +505,11 @@ NtArgsB nt_rows_b(NtArgsB a, int64_t r0, int64_t rows) {
 
 }  // namespace
 
-extern "C" int hwgat_linear_nt_bf16(const void* A, const void* W, const float* bias, void* C, int64_t M, int N,
-                                    int K, int pro, const float* mean, const float* rstd, const float* gamma,
-                                    const float* beta, uint32_t pro_seed, float pro_p, int epi, const void* res,
-                                    void* C2, const void* aux, uint32_t epi_seed, float epi_p, void* stream) {
+extern "C" int hwgat_linear_nt_bf16_ex(const void* A, const void* W, const float* bias, void* C, int64_t M, int N,
+                                       int K, int pro, const float* mean, const float* rstd, const float* gamma,
+                                       const float* beta, uint32_t pro_seed, float pro_p, int epi, const void* res,
+                                       void* C2, const void* aux, uint32_t epi_seed, float epi_p, float* stat_sum,
+                                       float* stat_sq, int merge_F, int merge_K, void* stream) {
     if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) return HWGAT_EINVAL;
     if (N % 128 || K % 64 || ((M + 127) / 128) * (int64_t)(N / 128) > 0x7fffffff) return HWGAT_ESHAPE;   // any M
     if (pro == PRO_LN && (!mean || !rstd || !gamma || !beta)) return HWGAT_EINVAL;
@@ -474,8 +518,14 @@ extern "C" int hwgat_linear_nt_bf16(const void* A, const void* W, const float* b
     if (epi == EPI_GELU_BWD && !aux) return HWGAT_EINVAL;
     if (pro_p < 0.f || pro_p >= 1.f || epi_p < 0.f || epi_p >= 1.f) return HWGAT_EINVAL;
     if (pro == PRO_DROP && pro_p == 0.f) pro = PRO_NONE;          // eval mode: no mask to hash
+    const bool stat = stat_sum != nullptr || stat_sq != nullptr || merge_K > 0;
+    if (stat) {
+        if (!stat_sum || !stat_sq || pro != PRO_NONE || epi != EPI_BIAS_DROP_RES) return HWGAT_EINVAL;
+        if (M % 256) return HWGAT_ESHAPE;
+        if (merge_K > 0 && (merge_F <= 0 || (merge_F & 1) || M % ((int64_t)merge_F * merge_K))) return HWGAT_EINVAL;
+    }
     NtArgsB a{(const bf16_t*)A, (const bf16_t*)W, bias, (bf16_t*)C, (bf16_t*)C2, (const bf16_t*)res,
-              (const bf16_t*)aux, mean, rstd, gamma, beta, M, N, K, pro_seed, epi_seed, pro_p, epi_p, 0};
+              (const bf16_t*)aux, mean, rstd, gamma, beta, M, N, K, pro_seed, epi_seed, pro_p, epi_p, 0, stat_sum, stat_sq, merge_K > 0 ? merge_F : 0, merge_K > 0 ? merge_K : 0};
     hipStream_t st = (hipStream_t)stream;
     const int64_t m_bulk = M / 128 * 128;                       // ragged token count: bulk launch + RAGGED tail launch
     if (m_bulk != M) {
@@ -518,6 +568,14 @@ extern "C" int hwgat_linear_nt_bf16(const void* A, const void* W, const float* b
         default: return HWGAT_EINVAL;
     }
 #undef NTB_GO
+}
+
+extern "C" int hwgat_linear_nt_bf16(const void* A, const void* W, const float* bias, void* C, int64_t M, int N,
+                                    int K, int pro, const float* mean, const float* rstd, const float* gamma,
+                                    const float* beta, uint32_t pro_seed, float pro_p, int epi, const void* res,
+                                    void* C2, const void* aux, uint32_t epi_seed, float epi_p, void* stream) {
+    return hwgat_linear_nt_bf16_ex(A, W, bias, C, M, N, K, pro, mean, rstd, gamma, beta, pro_seed, pro_p, epi, res, C2, aux,
+                                   epi_seed, epi_p, nullptr, nullptr, 0, 0, stream);
 }
 
 extern "C" int hwgat_linear_tn_bf16(const void* A, const void* B, float* dW, float* db, int64_t M, int N, int K,

@@ -37,7 +37,8 @@ __device__ __forceinline__ void pin() {
     }
 }
 
-template <int PRO, int EPI>
+// STAT: 0 = plain epilogue, 1 = + row statistics, 2 = + row statistics and the merged store (separate instantiations)
+template <int PRO, int EPI, int STAT = 0>
 __global__ __launch_bounds__(256, 1) void gemm_nt256_bf16_k(NtArgsB p) {
     __shared__ __attribute__((aligned(16))) unsigned char smb[2 * BUFB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -204,6 +205,10 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_bf16_k(NtArgsB p) {
             const float epi_sc = 1.0f / (1.0f - p.epi_p);
             float* stg = reinterpret_cast<float*>(smb + (buf ^ 1) * BUFB) + wave * (32 * SLD);
             const int er = lane >> 4, ec = (lane & 15) * 8;     // pass ps covers rows 4 ps + er, columns ec..ec+7
+            // per-row partial (sum, sum of squares) of each column half: [wn][256][2] behind the staging strips; every
+            // slot has exactly one writer (plain LDS stores, no atomics, nothing to zero)
+            float* rowstat = reinterpret_cast<float*>(smb + (buf ^ 1) * BUFB) + 4 * (32 * SLD);
+            static_assert(STAT == 0 || (4 * 32 * SLD + 4 * BT) * 4 <= BUFB, "no room for the row statistics");
             const int col = n0 + wn * 128 + ec;
             f32x4 bv0 = {0.f, 0.f, 0.f, 0.f}, bv1 = bv0;
             if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_DROP_RES || EPI == EPI_BIAS_GELU_DROP)
@@ -212,6 +217,8 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_bf16_k(NtArgsB p) {
             for (int i = 0; i < 4; ++i) {
                 const int64_t off0 = (m0 + wm * 128 + i * 32 + er) * p.N + col;       // row 4 ps + er: + 4 ps N
                 const int64_t rs4 = 4 * (int64_t)p.N;
+                MergeWalk mw;
+                if constexpr (STAT == 2) mw.start(m0 + wm * 128 + i * 32 + er, p.mg_F, p.mg_K, 4);
                 u32x4 ex[8];                                    // residual / pre-activation of the piece: in flight while it is parked
                 if constexpr (EPI == EPI_BIAS_DROP_RES || EPI == EPI_GELU_BWD) {
                     const bf16_t* src = (EPI == EPI_BIAS_DROP_RES ? p.res : p.aux) + off0;
@@ -255,10 +262,35 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_bf16_k(NtArgsB p) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) o8[e] = o8[e] * dk[e] * gelu_grad(h[e]);
                     }
-                    *reinterpret_cast<u32x4*>(p.C + off) = pack8(o8);
+                    const u32x4 outv = pack8(o8);
+                    if constexpr (STAT != 0) {                  // statistics of what the next LayerNorm will read: the bf16 values
+                        float q[8];
+                        unpack8(outv, q);
+                        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { s1 += q[e]; s2 += q[e] * q[e]; }
+                        s1 = group_sum<16>(s1); s2 = group_sum<16>(s2);
+                        const int lr = wm * 128 + i * 32 + 4 * ps + er;
+                        if ((lane & 15) == 0) { f32x2 st = {s1, s2}; *reinterpret_cast<f32x2*>(rowstat + (wn * BT + lr) * 2) = st; }
+                        if constexpr (STAT == 2) {
+                            *reinterpret_cast<u32x4*>(p.C + mw.off(p.N) + col) = outv;
+                            mw.next();
+                        } else {
+                            *reinterpret_cast<u32x4*>(p.C + off) = outv;
+                        }
+                    } else {
+                        *reinterpret_cast<u32x4*>(p.C + off) = outv;
+                    }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
+            }
+            if constexpr (STAT != 0) {
+                __syncthreads();
+                int64_t mr = m0 + tid;
+                if constexpr (STAT == 2) { MergeWalk w; w.start(m0 + tid, p.mg_F, p.mg_K, 1); mr = w.mrow(); }
+                atomicAdd(p.stat_sum + mr, rowstat[2 * tid] + rowstat[2 * (BT + tid)]);
+                atomicAdd(p.stat_sq + mr, rowstat[2 * tid + 1] + rowstat[2 * (BT + tid) + 1]);
             }
         }
         __syncthreads();            // staging lives in buf^1, which the next tile's second slab overwrites
@@ -270,6 +302,14 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_bf16_k(NtArgsB p) {
 
 template <int PRO>
 int launch(const NtArgsB& a, int epi, int grid, hipStream_t st) {
+    if (a.stat_sum != nullptr) {                                // validated by the caller: PRO_NONE, EPI_BIAS_DROP_RES
+        if constexpr (PRO == PRO_NONE) {
+            if (a.mg_K > 0) gemm_nt256_bf16_k<PRO_NONE, EPI_BIAS_DROP_RES, 2><<<grid, 256, 0, st>>>(a);
+            else gemm_nt256_bf16_k<PRO_NONE, EPI_BIAS_DROP_RES, 1><<<grid, 256, 0, st>>>(a);
+            HWGAT_LAUNCH_CHECK();
+        }
+        return HWGAT_EINVAL;
+    }
     switch (epi) {
         case EPI_BIAS: gemm_nt256_bf16_k<PRO, EPI_BIAS><<<grid, 256, 0, st>>>(a); break;
         case EPI_BIAS_DROP_RES: gemm_nt256_bf16_k<PRO, EPI_BIAS_DROP_RES><<<grid, 256, 0, st>>>(a); break;

@@ -17,16 +17,31 @@ struct NtArgs {
     int mg_F, mg_K;
 };
 
-// destination of output row m under the merged store (frames F, tokens per frame K, row width N): merged row index
-// and element offset of its first column
-__device__ __forceinline__ void merge_row(int64_t m, int F, int K, int N, int64_t& mrow, int64_t& off) {
-    const int64_t fr = m / K;                 // b * F + f
-    const int k = (int)(m - fr * K);
-    const int64_t b = fr / F;
-    const int f = (int)(fr - b * F);
-    mrow = (b * (F >> 1) + (f >> 1)) * K + k;
-    off = mrow * (2 * (int64_t)N) + (int64_t)(f & 1) * N;
-}
+// destination of output row m under the merged store: row (b, f, k) -> merged row (b, f/2, k), column offset (f & 1) N.
+// For a lane that walks rows m, m + step, m + 2 step, ... of one tile: ONE pair of 32-bit divisions
+// (rows of a launch are < 2^31), then carries.  step < K.
+struct MergeWalk {
+    int k, f; int64_t b; int F, K, step;
+    __device__ __forceinline__ void start(int64_t m, int F_, int K_, int step_) {
+        F = F_; K = K_; step = step_;
+        const uint32_t mm = (uint32_t)m, fr = mm / (uint32_t)K_;
+        k = (int)(mm - fr * (uint32_t)K_);
+        const uint32_t bb = fr / (uint32_t)F_;
+        f = (int)(fr - bb * (uint32_t)F_);
+        b = bb;
+    }
+    __device__ __forceinline__ int64_t mrow() const { return (b * (F >> 1) + (f >> 1)) * K + k; }
+    __device__ __forceinline__ int64_t off(int N) const { return mrow() * (2 * (int64_t)N) + (int64_t)(f & 1) * N; }
+    __device__ __forceinline__ void next() {
+        k += step;
+        const bool wk = k >= K;
+        k -= wk ? K : 0;
+        f += wk ? 1 : 0;
+        const bool wf = f >= F;
+        f -= wf ? F : 0;
+        b += wf ? 1 : 0;
+    }
+};
 
 struct TnArgs {
     const float* A; const float* B; float* dW; float* db;

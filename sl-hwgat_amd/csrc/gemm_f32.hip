@@ -51,7 +51,8 @@ using NtK16 = TileCfg<2, 2, 2, 2, 16, 3>;                      // 41 KB LDS -> 3
 // STAT (EPI_BIAS_DROP_RES only): the epilogue also produces the LayerNorm statistics of its OUTPUT rows (sum and sum
 // of squares, reduced per tile in LDS, then one coalesced run of global atomics per tile) and can store in the
 // TemporalMerging layout -- see NtArgs.  It is a separate instantiation: the plain launches stay the measured code.
-template <int PRO, int EPI, typename C, bool RAGGED = false, bool STAT = false>
+// (STAT: 0 = plain, 1 = + row statistics, 2 = + row statistics and the merged store)
+template <int PRO, int EPI, typename C, bool RAGGED = false, int STAT = 0>
 __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt_k(NtArgs p) {
     constexpr int BM = C::BM, BN = C::BN, TMW = C::TMW, TNW = C::TNW, PA = C::PA, PW = C::PW, RPP = C::RPP;
     constexpr int BK = C::BK, LDT = C::LDT;
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt
             float* stg = sm + (buf ^ 1) * ((BM + BN) * LDT) + wave * (32 * SLD);
             const int er = lane / LPR, ec = (lane % LPR) * 4;
             float* rowstat = sm + (buf ^ 1) * ((BM + BN) * LDT) + (C::THREADS / 64) * (32 * SLD);   // [BM][2] behind the staging
-            if constexpr (STAT) {
+            if constexpr (STAT != 0) {
                 static_assert((C::THREADS / 64) * 32 * SLD + 2 * BM <= (BM + BN) * LDT, "no room for the row statistics");
                 for (int q = tid; q < 2 * BM; q += C::THREADS) rowstat[q] = 0.f;
                 __syncthreads();
@@ -210,6 +211,8 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt
                     // parked, so NPS loads per lane are in flight together (they used to be issued pass by pass, two
                     // at a time, each paying an HBM round trip: the GELU-backward launch, whose largest stream this
                     // is, ran at 99 TFLOP/s against 130 for the plain product)
+                    MergeWalk mw;
+                    if constexpr (STAT == 2) mw.start(m0 + wm * (TMW * 32) + i * 32 + er, p.mg_F, p.mg_K, RPS);
                     f32x4 ex[NPS];
                     if constexpr (EPI == EPI_BIAS_DROP_RES || EPI == EPI_GELU_BWD) {
                         const float* src = EPI == EPI_BIAS_DROP_RES ? p.res : p.aux;
@@ -249,18 +252,20 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt
                             v.x *= dk.x * gelu_grad(h.x); v.y *= dk.y * gelu_grad(h.y);
                             v.z *= dk.z * gelu_grad(h.z); v.w *= dk.w * gelu_grad(h.w);
                         }
-                        if constexpr (STAT) {
+                        if constexpr (STAT != 0) {
                             float s1 = (v.x + v.y) + (v.z + v.w), s2 = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-#pragma unroll
-                            for (int o = LPR / 2; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+                            s1 = group_sum<LPR>(s1); s2 = group_sum<LPR>(s2);
                             if ((lane % LPR) == 0) {
                                 const int lr = wm * (TMW * 32) + i * 32 + rr;
                                 atomicAdd(rowstat + 2 * lr, s1);
                                 atomicAdd(rowstat + 2 * lr + 1, s2);
                             }
-                            int64_t doff = off;
-                            if (p.mg_K > 0) { int64_t mr; merge_row(grow, p.mg_F, p.mg_K, p.N, mr, doff); doff += col; }
-                            *reinterpret_cast<f32x4*>(p.C + doff) = v;
+                            if constexpr (STAT == 2) {
+                                *reinterpret_cast<f32x4*>(p.C + mw.off(p.N) + col) = v;
+                                mw.next();
+                            } else {
+                                *reinterpret_cast<f32x4*>(p.C + off) = v;
+                            }
                         } else {
                             *reinterpret_cast<f32x4*>(p.C + off) = v;
                         }
@@ -269,11 +274,11 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt
                     __builtin_amdgcn_wave_barrier();
                 }
             }
-            if constexpr (STAT) {
+            if constexpr (STAT != 0) {
                 __syncthreads();
                 for (int q = tid; q < BM; q += C::THREADS) {            // consecutive rows -> coalesced global atomics
-                    int64_t mr = m0 + q, doff;
-                    if (p.mg_K > 0) merge_row(m0 + q, p.mg_F, p.mg_K, p.N, mr, doff);
+                    int64_t mr = m0 + q;
+                    if constexpr (STAT == 2) { MergeWalk w; w.start(m0 + q, p.mg_F, p.mg_K, 1); mr = w.mrow(); }
                     atomicAdd(p.stat_sum + mr, rowstat[2 * q]);
                     atomicAdd(p.stat_sq + mr, rowstat[2 * q + 1]);
                 }
@@ -471,7 +476,8 @@ int launch_nt(const NtArgs& a, int epi, hipStream_t st) {
     const int grid = (int)(tiles < C::SLOTS ? tiles : C::SLOTS);      // persistent over tiles
     if (a.stat_sum != nullptr) {                                        // validated by the caller: PRO_NONE, EPI_BIAS_DROP_RES, M % 128 == 0
         if constexpr (PRO == PRO_NONE && !RAGGED) {
-            gemm_nt_k<PRO_NONE, EPI_BIAS_DROP_RES, C, false, true><<<grid, C::THREADS, 0, st>>>(a);
+            if (a.mg_K > 0) gemm_nt_k<PRO_NONE, EPI_BIAS_DROP_RES, C, false, 2><<<grid, C::THREADS, 0, st>>>(a);
+            else gemm_nt_k<PRO_NONE, EPI_BIAS_DROP_RES, C, false, 1><<<grid, C::THREADS, 0, st>>>(a);
             HWGAT_LAUNCH_CHECK();
         }
         return HWGAT_EINVAL;

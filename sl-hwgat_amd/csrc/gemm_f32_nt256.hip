@@ -52,7 +52,9 @@ __device__ __forceinline__ void pin() {
 
 // STAT (EPI_BIAS_DROP_RES only): row sums / sums of squares of the output for the next LayerNorm and the optional
 // TemporalMerging store, exactly as in gemm_nt_k (see NtArgs in gemm_f32.h)
-template <int PRO, int EPI, bool STAT = false>
+// (STAT: 0 = plain epilogue, 1 = + row statistics, 2 = + row statistics and the merged store: separate instantiations,
+//  because the merged store's index arithmetic would otherwise sit, as a branch per pass, in every epilogue)
+template <int PRO, int EPI, int STAT = 0>
 __global__ __launch_bounds__(256, 1) void gemm_nt256_k(NtArgs p) {
     __shared__ __attribute__((aligned(16))) float sm[2 * BUF];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -212,13 +214,10 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_k(NtArgs p) {
             const float epi_sc = 1.0f / (1.0f - p.epi_p);
             float* stg = sm + (buf ^ 1) * BUF + wave * (32 * SLD);
             const int er = lane >> 5, ec = (lane & 31) * 4;     // pass ps covers rows 2 ps + er, floats ec..ec+3
-            float* rowstat = sm + (buf ^ 1) * BUF + 4 * (32 * SLD);               // [256][2] behind the staging strips
-            if constexpr (STAT) {
-                static_assert(4 * 32 * SLD + 2 * BT <= BUF, "no room for the row statistics");
-                rowstat[tid] = 0.f;
-                rowstat[tid + 256] = 0.f;
-                __syncthreads();
-            }
+            // per-row partial (sum, sum of squares) of each column half: [wn][256][2] behind the staging strips; every
+            // slot has exactly one writer (plain LDS stores, no atomics, nothing to zero)
+            float* rowstat = sm + (buf ^ 1) * BUF + 4 * (32 * SLD);
+            static_assert(STAT == 0 || 4 * 32 * SLD + 4 * BT <= BUF, "no room for the row statistics");
             const int col = n0 + wn * 128 + ec;
             f32x4 bv = {0.f, 0.f, 0.f, 0.f};
             if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_DROP_RES || EPI == EPI_BIAS_GELU_DROP)
@@ -227,6 +226,8 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_k(NtArgs p) {
             for (int i = 0; i < 4; ++i) {
                 const int64_t off0 = (m0 + wm * 128 + i * 32 + er) * p.N + col;       // row 2 ps + er: + 2 ps N
                 const int64_t rs2 = 2 * (int64_t)p.N;
+                MergeWalk mw;
+                if constexpr (STAT == 2) mw.start(m0 + wm * 128 + i * 32 + er, p.mg_F, p.mg_K, 2);
                 // operands of this piece (residual / pre-activation): in flight while the piece is parked
                 f32x4 ex[16];
                 if constexpr (EPI == EPI_BIAS_DROP_RES || EPI == EPI_GELU_BWD) {
@@ -259,15 +260,17 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_k(NtArgs p) {
                         v.x *= dk.x * gelu_grad(h.x); v.y *= dk.y * gelu_grad(h.y);
                         v.z *= dk.z * gelu_grad(h.z); v.w *= dk.w * gelu_grad(h.w);
                     }
-                    if constexpr (STAT) {
+                    if constexpr (STAT != 0) {
                         float s1 = (v.x + v.y) + (v.z + v.w), s2 = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-#pragma unroll
-                        for (int o = 16; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+                        s1 = group_sum<32>(s1); s2 = group_sum<32>(s2);
                         const int lr = wm * 128 + i * 32 + 2 * ps + er;
-                        if ((lane & 31) == 0) { atomicAdd(rowstat + 2 * lr, s1); atomicAdd(rowstat + 2 * lr + 1, s2); }
-                        int64_t doff = off;
-                        if (p.mg_K > 0) { int64_t mr; merge_row(m0 + lr, p.mg_F, p.mg_K, p.N, mr, doff); doff += col; }
-                        *reinterpret_cast<f32x4*>(p.C + doff) = v;
+                        if ((lane & 31) == 0) { f32x2 st = {s1, s2}; *reinterpret_cast<f32x2*>(rowstat + (wn * BT + lr) * 2) = st; }
+                        if constexpr (STAT == 2) {
+                            *reinterpret_cast<f32x4*>(p.C + mw.off(p.N) + col) = v;
+                            mw.next();
+                        } else {
+                            *reinterpret_cast<f32x4*>(p.C + off) = v;
+                        }
                     } else {
                         *reinterpret_cast<f32x4*>(p.C + off) = v;
                     }
@@ -275,12 +278,12 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_k(NtArgs p) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             }
-            if constexpr (STAT) {
+            if constexpr (STAT != 0) {
                 __syncthreads();
-                int64_t mr = m0 + tid, doff;                    // 256 consecutive rows -> coalesced global atomics
-                if (p.mg_K > 0) merge_row(m0 + tid, p.mg_F, p.mg_K, p.N, mr, doff);
-                atomicAdd(p.stat_sum + mr, rowstat[2 * tid]);
-                atomicAdd(p.stat_sq + mr, rowstat[2 * tid + 1]);
+                int64_t mr = m0 + tid;                          // 256 consecutive rows -> coalesced global atomics
+                if constexpr (STAT == 2) { MergeWalk w; w.start(m0 + tid, p.mg_F, p.mg_K, 1); mr = w.mrow(); }
+                atomicAdd(p.stat_sum + mr, rowstat[2 * tid] + rowstat[2 * (BT + tid)]);
+                atomicAdd(p.stat_sq + mr, rowstat[2 * tid + 1] + rowstat[2 * (BT + tid) + 1]);
             }
         }
         __syncthreads();            // staging lives in buf^1, which the next tile's second slab overwrites
@@ -294,7 +297,8 @@ template <int PRO>
 int launch(const NtArgs& a, int epi, int grid, hipStream_t st) {
     if (a.stat_sum != nullptr) {                                // validated by the caller: PRO_NONE, EPI_BIAS_DROP_RES
         if constexpr (PRO == PRO_NONE) {
-            gemm_nt256_k<PRO_NONE, EPI_BIAS_DROP_RES, true><<<grid, 256, 0, st>>>(a);
+            if (a.mg_K > 0) gemm_nt256_k<PRO_NONE, EPI_BIAS_DROP_RES, 2><<<grid, 256, 0, st>>>(a);
+            else gemm_nt256_k<PRO_NONE, EPI_BIAS_DROP_RES, 1><<<grid, 256, 0, st>>>(a);
             HWGAT_LAUNCH_CHECK();
         }
         return HWGAT_EINVAL;

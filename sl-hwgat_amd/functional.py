@@ -329,15 +329,15 @@ EPI_BIAS, EPI_BIAS_DROP_RES, EPI_BIAS_GELU_DROP, EPI_GELU_BWD, EPI_NONE = 0, 1, 
 
 
 def can_fuse_row_stats(x):
-    """the producing linear's epilogue can deliver the LayerNorm statistics of `x`-shaped output (fp32, whole tiles)"""
-    return x.dtype == torch.float32 and (x.numel() // x.shape[-1]) % 256 == 0
+    """the producing linear's epilogue can deliver the LayerNorm statistics of `x`-shaped output (whole tiles)"""
+    return (x.numel() // x.shape[-1]) % 256 == 0
 
 
 def linear_nt(A, W, bias=None, *, pro=PRO_NONE, ln=None, pro_seed=0, pro_p=0.0, epi=EPI_BIAS,
               res=None, aux=None, epi_seed=0, epi_p=0.0, out=None, stats=False, merge=None):
     """C[M,N] = pro(A)[M,K] . W[N,K]^T with fused epilogue (see include/hwgat_hip.h).
     Returns C, or (C, C2) for EPI_BIAS_GELU_DROP (C2 = pre-activation).
-    EPI_BIAS_DROP_RES, fp32 only: `stats=True` also returns (mean, rstd) of the OUTPUT rows, produced by the epilogue
+    EPI_BIAS_DROP_RES: `stats=True` also returns (mean, rstd) of the OUTPUT rows, produced by the epilogue
     (no separate pass over C); `merge=(F, K_tok)` stores C in the TemporalMerging layout (B, F/2, K_tok, 2N)
     (HWGATE.py:55-63), statistics then per merged row.  Returns (C, mean, rstd)."""
     K = A.shape[-1]
@@ -346,8 +346,8 @@ def linear_nt(A, W, bias=None, *, pro=PRO_NONE, ln=None, pro_seed=0, pro_p=0.0, 
     if W.dtype != A.dtype:
         raise TypeError("weight must already be in the activation dtype (cast once per step)")
     if stats or merge is not None:
-        if A.dtype != torch.float32 or epi != EPI_BIAS_DROP_RES or pro != PRO_NONE or M % 256 or out is not None:
-            raise ValueError("row statistics / merged store: fp32, EPI_BIAS_DROP_RES, no prologue, M % 256 == 0")
+        if epi != EPI_BIAS_DROP_RES or pro != PRO_NONE or M % 256 or out is not None:
+            raise ValueError("row statistics / merged store: EPI_BIAS_DROP_RES, no prologue, M % 256 == 0")
         if merge is not None:
             F, Kt = merge
             C = torch.empty(M // (F * Kt), F // 2, Kt, 2 * N, device=A.device, dtype=A.dtype)
@@ -356,7 +356,8 @@ def linear_nt(A, W, bias=None, *, pro=PRO_NONE, ln=None, pro_seed=0, pro_p=0.0, 
             C = torch.empty(*A.shape[:-1], N, device=A.device, dtype=A.dtype)
             rows, width = M, N
         st = torch.zeros(2, rows, device=A.device, dtype=torch.float32)
-        call("hwgat_linear_nt_f32_ex", ptr(A), ptr(W), ptr(bias), ptr(C), M, N, K, pro, None, None, None, None,
+        call("hwgat_linear_nt_f32_ex" if A.dtype == torch.float32 else "hwgat_linear_nt_bf16_ex",
+             ptr(A), ptr(W), ptr(bias), ptr(C), M, N, K, pro, None, None, None, None,
              pro_seed & 0xFFFFFFFF, float(pro_p), epi, ptr(res), None, None, epi_seed & 0xFFFFFFFF, float(epi_p),
              ptr(st[0]), ptr(st[1]), merge[0] if merge else 0, merge[1] if merge else 0, stream())
         call("hwgat_ln_finalize", ptr(st[0]), ptr(st[1]), rows, width, stream())

@@ -333,16 +333,17 @@ def test_nt_persistent_tile_loop_every_prologue_and_epilogue(M, N, K, pro, epi):
     assert bool(torch.isfinite(got).all())
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("M,N,K,F,Kt", [(256 * 6, 128, 256, 4, 96), (256 * 40, 256, 512, 8, 80), (256 * 1500, 128, 128, 6, 64000)])
-def test_nt_epilogue_row_statistics_and_merged_store(M, N, K, F, Kt):
+def test_nt_epilogue_row_statistics_and_merged_store(M, N, K, F, Kt, dtype):
     """hwgat_linear_nt_f32_ex: the dropout + residual epilogue also delivers mean / rstd of its OUTPUT rows (the next
     LayerNorm's statistics, no separate pass) and can store in the TemporalMerging layout (HWGATE.py:55-63)."""
     p = 0.1
     g = torch.Generator(device=DEV).manual_seed(M + N)
-    A = torch.randn(M, K, device=DEV, generator=g)
-    W = torch.randn(N, K, device=DEV, generator=g) * 0.1
+    A = torch.randn(M, K, device=DEV, generator=g).to(dtype)
+    W = (torch.randn(N, K, device=DEV, generator=g) * 0.1).to(dtype)
     b = torch.randn(N, device=DEV, generator=g)
-    res = torch.randn(M, N, device=DEV, generator=g) + 0.7            # a non-zero row mean
+    res = (torch.randn(M, N, device=DEV, generator=g) + 0.7).to(dtype)            # a non-zero row mean
     plain = HF.linear_nt(A, W, b, epi=HF.EPI_BIAS_DROP_RES, res=res, epi_seed=9, epi_p=p)
     out, mean, rstd = HF.linear_nt(A, W, b, epi=HF.EPI_BIAS_DROP_RES, res=res, epi_seed=9, epi_p=p, stats=True)
     assert torch.equal(out, plain)

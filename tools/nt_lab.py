@@ -60,10 +60,20 @@ for i in stages:
         ("d_o   drop -> plain      ", M, d, d, lambda: HF.linear_nt(x, w_p_t, None, pro=HF.PRO_DROP, pro_seed=1, pro_p=.1, epi=HF.EPI_NONE, out=o1)),
         ("d_xn  plain              ", M, d, 3 * d, lambda: HF.linear_nt(y3, w_qkv_t, None, epi=HF.EPI_NONE, out=o1)),
     ]
+    if os.environ.get("NT_LAB_STATS") == "1":       # the same two launches with the statistics (and merged-store) epilogue
+        cases += [
+            ("proj  +row statistics     ", M, d, d, lambda: HF.linear_nt(x, w_p, b1, epi=HF.EPI_BIAS_DROP_RES, res=res, epi_seed=1, epi_p=.1, stats=True)),
+            ("fc2   +row statistics     ", M, d, 2 * d, lambda: HF.linear_nt(u2, w2, b1, epi=HF.EPI_BIAS_DROP_RES, res=res, epi_seed=3, epi_p=.1, stats=True)),
+            ("fc2   +statistics, merged ", M, d, 2 * d, lambda: HF.linear_nt(u2, w2, b1, epi=HF.EPI_BIAS_DROP_RES, res=res, epi_seed=3, epi_p=.1, stats=True, merge=(T >> i, K))),
+        ]
     for name, m, n, k, fn in cases:
         t = bench(fn)
         fl = 2.0 * m * n * k
-        total += t * depth
+        if "statistics" not in name:
+            total += t * depth
+        if "statistics" in name:
+            print(f"stage {i} d={d:4d} {name} M={m} N={n:4d} K={k:4d}: {t * 1e6:8.1f} us  {fl / t / 1e12:6.1f} TF   (incl. zero-fill + finalize)", flush=True)
+            continue
         mult = {"qkv ": 4, "proj": 3, "fc1 ": 5, "fc2 ": 4, "d_h1": 5, "d_z ": 3, "d_o ": 2, "d_xn": 4}[name[:4].ljust(4)]      # E-sized streams
         gb = mult * m * d * esz
         print(f"stage {i} d={d:4d} {name} M={m} N={n:4d} K={k:4d}: {t * 1e6:8.1f} us  {fl / t / 1e12:6.1f} TF  {gb / t / 1e12:5.2f} TB/s", flush=True)
