@@ -390,6 +390,7 @@ def main():
         b_launch = min(args.micro_batch or c["B"], c["B"])            # clips per attention launch
         E = b_launch * c["T"] * K * c["d0"]
         kern = {}
+        hip_ms = sum(v[1] for v in timers.values())                  # every timed C-ABI entry point, before any merging below
         attn = "hwgat_blk_attn" if hgate else "hwgat_band_attn" if wgate else "hwgat_win_attn"
         for name, bwd in ((attn + "_fwd", False), (attn + "_bwd", True)):
             n, ms = timers.get(name, (0, 0.0))
@@ -429,7 +430,6 @@ def main():
                               "flops_per_step": fl}
         others = {k: {"launches": v[0], "total_ms": round(v[1], 3)} for k, v in timers.items()
                   if k not in kern}
-        hip_ms = sum(v[1] for v in timers.values())
         roof = dict(kern.get(attn + "_bwd", {"bound": "hbm", "achieved": None, "peak": HBM_PEAK / 1e9,
                                                     "unit": "GB/s", "frac": None, "traffic": None}))
         roof["kernel"] = ("blk_attn_bwd_k (fused block graph-attention backward, HGATE)" if hgate

@@ -164,6 +164,9 @@ int hwgat_merge(const void* in, void* out, int B, int F, int K, int d, int inver
  *   (a ragged last 128-row block clamps its loads to row M-1 and guards its stores).
  *   pro: 0 none | 1 LayerNorm: (A-mean[m])*rstd[m]*gamma[k]+beta[k] | 2 dropout mask on A
  *        (keep-scale 1/(1-pro_p), element index m*K+k, seed pro_seed)
+ *        | 3 folded LayerNorm (hwgat_ln_fold below): A is the un-normalised input, W = W o gamma, gamma = s[N],
+ *        beta = c[N], bias ignored; the epilogue forms rstd[m] (acc - mean[m] s[n]) + c[n] -- the value of pro 1 up
+ *        to rounding, with the per-element normalisation out of the load path; epi 0 or 2 only, M % 128 == 0
  *   epi: 0  C = acc + bias
  *        1  C = res + dropout(acc + bias)             (mask index m*N+n, seed epi_seed)
  *        2  C2 = acc + bias ; C = dropout(gelu(C2))   (exact-erf GELU)
@@ -190,6 +193,13 @@ int hwgat_linear_nt_f32_ex(const float* A, const float* W, const float* bias, fl
                            const float* beta, uint32_t pro_seed, float pro_p, int epi, const float* res,
                            float* C2, const float* aux, uint32_t epi_seed, float epi_p, float* stat_sum,
                            float* stat_sq, int merge_F, int merge_K, void* stream);
+
+/* Weights of a Linear that follows a LayerNorm (norm1 -> qkv, HWGATE.py:203-205 / :86; norm2 -> fc1, :219 / :131),
+ * folded for pro = 3 of the NT launches:  Wf[n,k] = W[n,k] gamma[k] in `dtype` (HWGAT_F32 / HWGAT_BF16),
+ * s[n] = sum_k Wf[n,k] (of the stored values), c[n] = bias[n] + sum_k beta[k] W[n,k].  W, bias, gamma, beta fp32
+ * (the master weights); bias may be NULL.  One launch per step and linear (N x K elements). */
+int hwgat_ln_fold(const float* W, const float* bias, const float* gamma, const float* beta, int N, int K,
+                  void* Wf, float* s, float* c, int dtype, void* stream);
 
 /* (row sum, row sum of squares) of a d-wide tensor -> (mean, rstd) in place, nn.LayerNorm's biased variance and
  * eps 1e-5 (HWGATE.py:162,166). */

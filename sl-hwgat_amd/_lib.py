@@ -41,6 +41,7 @@ _SIGS = {
     "hwgat_linear_nt_f32_ex": [_P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _P, _U, _F, _I, _P, _P, _P, _U, _F, _P, _P, _I, _I, _P],
     "hwgat_linear_nt_bf16_ex": [_P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _P, _U, _F, _I, _P, _P, _P, _U, _F, _P, _P, _I, _I, _P],
     "hwgat_ln_finalize": [_P, _P, _L, _I, _P],
+    "hwgat_ln_fold": [_P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _P],
     "hwgat_linear_tn_f32": [_P, _P, _P, _P, _L, _I, _I, _U, _F, _P, _P, _P, _P, _P],
     "hwgat_linear_nt_bf16": [_P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _P, _U, _F, _I, _P, _P, _P, _U, _F, _P],
     "hwgat_linear_tn_bf16": [_P, _P, _P, _P, _L, _I, _I, _U, _F, _P, _P, _P, _P, _P],

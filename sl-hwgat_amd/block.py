@@ -4,7 +4,8 @@ node whose forward and backward are sequences of HIP launches only.
 forward  (4 GEMM launches + 1 attention; the reference runs ~40 ATen ops):
     stats1           = LN statistics of x: handed over by the PREVIOUS block's fc2 epilogue, or one hwgat_ln_fwd(y=NULL)
                        pass for the first block (and whenever the epilogue cannot produce them: bf16, ragged M)
-    qkv              = LN1(x) Wqkv^T + b        LN applied in the GEMM prologue
+    qkv              = LN1(x) Wqkv^T + b        LN folded into the weights and the GEMM epilogue (hwgat_ln_fold, pro 3);
+                       ragged token counts: applied by the GEMM's loader (pro 1)
     o                = window attention(qkv)                           (hwgat_win_attn_fwd)
     y                = x + drop(o Wp^T + b)     bias+dropout+residual in the GEMM epilogue, which also accumulates the
                        row sums / sums of squares of y -> stats2 (hwgat_linear_nt_f32_ex + hwgat_ln_finalize)
@@ -75,7 +76,7 @@ class _FusedBlock(torch.autograd.Function):
         fuse = HF.can_fuse_row_stats(x)           # the producing epilogue delivers the LayerNorm statistics
         if m1 is None:
             m1, r1 = HF.ln_stats(x, n1w, n1b)
-        qkv = HF.linear_nt(x, cw(wqkv), bqkv, pro=HF.PRO_LN, ln=(m1, r1, n1w, n1b))
+        qkv = HF.linear_nt_ln(x, wqkv, bqkv, (m1, r1, n1w, n1b))
         o = torch.empty_like(x)
         HF.attn_fwd(kind, qkv, o, bits, thr, n_heads, shifted)
         if fuse:
@@ -83,8 +84,7 @@ class _FusedBlock(torch.autograd.Function):
         else:
             y = HF.linear_nt(o, cw(wp), bp, epi=HF.EPI_BIAS_DROP_RES, res=x, epi_seed=seeds[0], epi_p=p)
             m2, r2 = HF.ln_stats(y, n2w, n2b)
-        u, h1 = HF.linear_nt(y, cw(w1), b1, pro=HF.PRO_LN, ln=(m2, r2, n2w, n2b), epi=HF.EPI_BIAS_GELU_DROP,
-                             epi_seed=seeds[1], epi_p=p)
+        u, h1 = HF.linear_nt_ln(y, w1, b1, (m2, r2, n2w, n2b), epi=HF.EPI_BIAS_GELU_DROP, epi_seed=seeds[1], epi_p=p)
         merged = bool(merge_out and fuse)
         if fuse and (want_stats or merged):
             out, mo, ro = HF.linear_nt(u, cw(w2), b2, epi=HF.EPI_BIAS_DROP_RES, res=y, epi_seed=seeds[2], epi_p=p,

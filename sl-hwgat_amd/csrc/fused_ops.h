@@ -2,7 +2,13 @@
 #pragma once
 #include "common.h"
 
-enum { PRO_NONE = 0, PRO_LN = 1, PRO_DROP = 2 };
+// PRO_LN_FOLD: LayerNorm of A folded into the weights and the epilogue (hwgat_ln_fold): the loaders see plain A, W is
+// W o gamma, and the epilogue turns the accumulator into rstd_m (acc - mean_m s_n) + c_n with s_n = sum_k W'[n,k] and
+// c_n = bias_n + sum_k beta_k W[n,k] (passed in the gamma / beta slots).  Same value as PRO_LN up to rounding; the
+// per-element normalisation leaves the load path, where it cost the qkv launch 14 % (fp32) to 33 % (bf16).
+enum { PRO_NONE = 0, PRO_LN = 1, PRO_DROP = 2, PRO_LN_FOLD = 3 };
+// extra work of an NT epilogue (template parameter STAT of the NT kernels)
+enum { X_NONE = 0, X_STAT = 1, X_STAT_MERGE = 2, X_LNFOLD = 3 };
 enum { EPI_BIAS = 0, EPI_BIAS_DROP_RES = 1, EPI_BIAS_GELU_DROP = 2, EPI_GELU_BWD = 3, EPI_NONE = 4 };
 
 // Dropout mask: a counter-based hash of (seed, element index).  One 32-bit hash serves an

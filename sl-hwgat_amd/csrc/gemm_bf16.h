@@ -58,4 +58,17 @@ __device__ __forceinline__ u32x4 pack8(const float (&v)[8]) {
 }
 
 // 256x256 C tile, 4 waves x (128x128), one wave per SIMD (gemm_bf16_nt256.hip); needs M % 256 == N % 256 == K % 64 == 0
+// dW / db launch record of the bf16 weight-gradient kernels (gemm_tn_bf16_k, gemm_tn256_bf16_k)
+struct TnArgsB {
+    const bf16_t* A; const bf16_t* B; float* dW; float* db;
+    const float* mean; const float* rstd; const float* gamma; const float* beta;
+    int64_t M; int N, K;
+    int n_split; int64_t rows_per_split;
+    uint32_t pro_seed; float pro_p;
+    int64_t row0;          // see NtArgsB
+};
+
+// defined in gemm_bf16_tn256.hip: 256x256 dW tiles; N % 256 == K % 256 == M % 32 == 0
+int hwgat_launch_tn256_bf16(TnArgsB a, hipStream_t st);
+
 int hwgat_launch_nt256_bf16(const NtArgsB& a, int pro, int epi, hipStream_t st);

@@ -169,7 +169,7 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt
         float* stg = reinterpret_cast<float*>(sm + idle * ((BM + BN) * LDT)) + wave * (32 * SLD);
         const int er = lane / LPR, ec = (lane % LPR) * 8;
         float* rowstat = reinterpret_cast<float*>(sm + idle * ((BM + BN) * LDT)) + (C::THREADS / 64) * (32 * SLD);   // [BM][2]
-        if constexpr (STAT != 0) {
+        if constexpr (STAT == X_STAT || STAT == X_STAT_MERGE) {
             static_assert(((C::THREADS / 64) * 32 * SLD + 2 * BM) * 4 <= (BM + BN) * LDT * 2, "no room for the row statistics");
             for (int q = tid; q < 2 * BM; q += C::THREADS) rowstat[q] = 0.f;
             __syncthreads();
@@ -180,10 +180,24 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt
             f32x4 bv0 = {0.f, 0.f, 0.f, 0.f}, bv1 = bv0;
             if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_DROP_RES || EPI == EPI_BIAS_GELU_DROP)
                 if (p.bias) { bv0 = *reinterpret_cast<const f32x4*>(p.bias + col); bv1 = *reinterpret_cast<const f32x4*>(p.bias + col + 4); }
+            f32x4 sv0 = bv0, sv1 = bv0, cv0 = bv0, cv1 = bv0;  // X_LNFOLD: s_n and c_n of the lane's 8 columns
+            if constexpr (STAT == X_LNFOLD) {
+                sv0 = *reinterpret_cast<const f32x4*>(p.gamma + col); sv1 = *reinterpret_cast<const f32x4*>(p.gamma + col + 4);
+                cv0 = *reinterpret_cast<const f32x4*>(p.beta + col); cv1 = *reinterpret_cast<const f32x4*>(p.beta + col + 4);
+            }
 #pragma unroll
             for (int i = 0; i < TMW; ++i) {
+                float rr_[NPS], rm[NPS];                        // X_LNFOLD: rstd and mean of the piece's rows
+                if constexpr (STAT == X_LNFOLD) {
+#pragma unroll
+                    for (int ps = 0; ps < NPS; ++ps) {
+                        int64_t grow = m0 + wm * (TMW * 32) + i * 32 + ps * RPS + er;
+                        if constexpr (RAGGED) grow = grow < m_last ? grow : m_last;
+                        rr_[ps] = p.rstd[grow]; rm[ps] = p.mean[grow];
+                    }
+                }
                 MergeWalk mw;
-                if constexpr (STAT == 2) mw.start(m0 + wm * (TMW * 32) + i * 32 + er, p.mg_F, p.mg_K, RPS);
+                if constexpr (STAT == X_STAT_MERGE) mw.start(m0 + wm * (TMW * 32) + i * 32 + er, p.mg_F, p.mg_K, RPS);
                 u32x4 ex[NPS];
                 if constexpr (EPI == EPI_BIAS_DROP_RES || EPI == EPI_GELU_BWD) {
                     const bf16_t* src = EPI == EPI_BIAS_DROP_RES ? p.res : p.aux;
@@ -207,8 +221,14 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt
                     const int64_t grow = m0 + wm * (TMW * 32) + i * 32 + rr;
                     if constexpr (RAGGED) { if (grow > m_last) continue; }
                     const int64_t off = grow * p.N + col;
-                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + rr * SLD + ec) + bv0;
-                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + rr * SLD + ec + 4) + bv1;
+                    f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + rr * SLD + ec);
+                    f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + rr * SLD + ec + 4);
+                    if constexpr (STAT == X_LNFOLD) {
+                        const float t = rm[ps] * rr_[ps];
+                        v0 = v0 * rr_[ps] + (cv0 - sv0 * t); v1 = v1 * rr_[ps] + (cv1 - sv1 * t);
+                    } else {
+                        v0 += bv0; v1 += bv1;
+                    }
                     float o8[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
                     float dk[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
                     if constexpr (EPI == EPI_BIAS_DROP_RES || EPI == EPI_BIAS_GELU_DROP || EPI == EPI_GELU_BWD) {
@@ -237,7 +257,7 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt
                         for (int e = 0; e < 8; ++e) o8[e] = o8[e] * dk[e] * gelu_grad(h[e]);
                     }
                     const u32x4 outv = pack8(o8);
-                    if constexpr (STAT != 0) {                  // statistics of the bf16 values the next LayerNorm reads
+                    if constexpr (STAT == X_STAT || STAT == X_STAT_MERGE) {                  // statistics of the bf16 values the next LayerNorm reads
                         float q[8];
                         unpack8(outv, q);
                         float s1 = 0.f, s2 = 0.f;
@@ -246,7 +266,7 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt
                         s1 = group_sum<LPR>(s1); s2 = group_sum<LPR>(s2);
                         const int lr = wm * (TMW * 32) + i * 32 + rr;
                         if ((lane % LPR) == 0) { atomicAdd(rowstat + 2 * lr, s1); atomicAdd(rowstat + 2 * lr + 1, s2); }
-                        if constexpr (STAT == 2) {
+                        if constexpr (STAT == X_STAT_MERGE) {
                             *reinterpret_cast<u32x4*>(p.C + mw.off(p.N) + col) = outv;
                             mw.next();
                         } else {
@@ -260,11 +280,11 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt
                 __builtin_amdgcn_wave_barrier();
             }
         }
-        if constexpr (STAT != 0) {
+        if constexpr (STAT == X_STAT || STAT == X_STAT_MERGE) {
             __syncthreads();
             for (int q = tid; q < BM; q += C::THREADS) {
                 int64_t mr = m0 + q;
-                if constexpr (STAT == 2) { MergeWalk w; w.start(m0 + q, p.mg_F, p.mg_K, 1); mr = w.mrow(); }
+                if constexpr (STAT == X_STAT_MERGE) { MergeWalk w; w.start(m0 + q, p.mg_F, p.mg_K, 1); mr = w.mrow(); }
                 atomicAdd(p.stat_sum + mr, rowstat[2 * q]);
                 atomicAdd(p.stat_sq + mr, rowstat[2 * q + 1]);
             }
@@ -306,14 +326,6 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt
 }
 
 // ------------------------------------------------------------------ dW / db (bf16 operands)
-struct TnArgsB {
-    const bf16_t* A; const bf16_t* B; float* dW; float* db;
-    const float* mean; const float* rstd; const float* gamma; const float* beta;
-    int64_t M; int N, K;
-    int n_split; int64_t rows_per_split;
-    uint32_t pro_seed; float pro_p;
-    int64_t row0;          // see NtArgsB
-};
 
 constexpr int TMB = 32;              // rows of M per LDS stage (two k16 steps)
 constexpr int LDW = 160;             // LDS row stride in bf16 (320 B): tr-read rows hit disjoint bank quarters
@@ -468,9 +480,18 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_k(TnArgsB p) {
 }
 
 template <int PRO, typename C, bool RAGGED = false>
-int launch_nt_b(const NtArgsB& a, int epi, hipStream_t st) {
+int launch_nt_b(const NtArgsB& a, int epi, hipStream_t st, bool fold = false) {
     const int64_t tiles = ((a.M + C::BM - 1) / C::BM) * (a.N / C::BN);
     const int grid = (int)(tiles < C::SLOTS ? tiles : C::SLOTS);
+    if (fold) {                                                 // PRO_LN_FOLD: plain loaders, row-affine epilogue
+        if constexpr (PRO == PRO_NONE) {
+            if (epi == EPI_BIAS) gemm_nt_bf16_k<PRO_NONE, EPI_BIAS, C, RAGGED, X_LNFOLD><<<grid, C::THREADS, 0, st>>>(a);
+            else if (epi == EPI_BIAS_GELU_DROP) gemm_nt_bf16_k<PRO_NONE, EPI_BIAS_GELU_DROP, C, RAGGED, X_LNFOLD><<<grid, C::THREADS, 0, st>>>(a);
+            else return HWGAT_EINVAL;
+            HWGAT_LAUNCH_CHECK();
+        }
+        return HWGAT_EINVAL;
+    }
     if (a.stat_sum != nullptr) {                                // validated by the caller: PRO_NONE, EPI_BIAS_DROP_RES, whole tiles
         if constexpr (PRO == PRO_NONE && !RAGGED) {
             if (a.mg_K > 0) gemm_nt_bf16_k<PRO_NONE, EPI_BIAS_DROP_RES, C, false, 2><<<grid, C::THREADS, 0, st>>>(a);
@@ -512,7 +533,11 @@ extern "C" int hwgat_linear_nt_bf16_ex(const void* A, const void* W, const float
                                        float* stat_sq, int merge_F, int merge_K, void* stream) {
     if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) return HWGAT_EINVAL;
     if (N % 128 || K % 64 || ((M + 127) / 128) * (int64_t)(N / 128) > 0x7fffffff) return HWGAT_ESHAPE;   // any M
-    if (pro == PRO_LN && (!mean || !rstd || !gamma || !beta)) return HWGAT_EINVAL;
+    if ((pro == PRO_LN || pro == PRO_LN_FOLD) && (!mean || !rstd || !gamma || !beta)) return HWGAT_EINVAL;
+    if (pro == PRO_LN_FOLD) {                                      // gamma = s[N], beta = c[N] of hwgat_ln_fold; whole tiles
+        if (epi != EPI_BIAS && epi != EPI_BIAS_GELU_DROP) return HWGAT_EINVAL;
+        if (M % 128) return HWGAT_ESHAPE;
+    }
     if (epi == EPI_BIAS_DROP_RES && !res) return HWGAT_EINVAL;
     if (epi == EPI_BIAS_GELU_DROP && !C2) return HWGAT_EINVAL;
     if (epi == EPI_GELU_BWD && !aux) return HWGAT_EINVAL;
@@ -555,6 +580,7 @@ extern "C" int hwgat_linear_nt_bf16_ex(const void* A, const void* W, const float
         const NtArgsB t = nt_rows_b(a, m256, M - m256);   // 128 rows left: RAGGED instantiation (global row index in the dropout hash)
         switch (pro) {
             case PRO_NONE: return launch_nt_b<PRO_NONE, NtB64, true>(t, epi, st);
+            case PRO_LN_FOLD: return launch_nt_b<PRO_NONE, NtB64, true>(t, epi, st, true);
             case PRO_LN: return launch_nt_b<PRO_LN, NtB64, true>(t, epi, st);
             case PRO_DROP: return launch_nt_b<PRO_DROP, NtB64, true>(t, epi, st);
             default: return HWGAT_EINVAL;
@@ -563,6 +589,7 @@ extern "C" int hwgat_linear_nt_bf16_ex(const void* A, const void* W, const float
 #define NTB_GO(P) return launch_nt_b<P, NtB64>(a, epi, st)
     switch (pro) {
         case PRO_NONE: NTB_GO(PRO_NONE);
+        case PRO_LN_FOLD: return launch_nt_b<PRO_NONE, NtB64>(a, epi, st, true);
         case PRO_LN: NTB_GO(PRO_LN);
         case PRO_DROP: NTB_GO(PRO_DROP);
         default: return HWGAT_EINVAL;
@@ -604,6 +631,16 @@ extern "C" int hwgat_linear_tn_bf16(const void* A, const void* B, float* dW, flo
             else gemm_tn_bf16_k<PRO_NONE, false, true><<<grid_t, 256, 0, stt>>>(t);
         }
         HWGAT_LAUNCH_CHECK();
+    }
+    // dW at least 256 x 256: the 128x128-wave-tile kernel (gemm_bf16_tn256.hip); HWGAT_TN_KERNEL=old keeps this file's
+    static const bool tn_old = [] { const char* e = getenv("HWGAT_TN_KERNEL"); return e && e[0] == 'o'; }();
+    // ... where its tiles fill the 256 CUs in whole rounds of equal blocks (tile count a divisor of 256: 1, 2, 4, 8 ...);
+    // 3 or 12 tiles (the qkv weight) need three rounds of short M slices and lose to the 128x128 kernel:
+    // stage 2 dWqkv 492 vs 454 us, stage 1 349 vs 272 (same box, tools/tn_lab.py)
+    const int t256 = (N / 256) * (K / 256);
+    if (!tn_old && N % 256 == 0 && K % 256 == 0 && M % 32 == 0 && 256 % t256 == 0 && !(pro_p > 0.f && mean)) {
+        TnArgsB a{(const bf16_t*)A, (const bf16_t*)B, dW, db, mean, rstd, gamma, beta, M, N, K, 1, M, pro_seed, pro_p, 0};
+        return hwgat_launch_tn256_bf16(a, (hipStream_t)stream);
     }
     const int n_tiles = (N / 128) * (K / 128);
     auto gcd = [](int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; };

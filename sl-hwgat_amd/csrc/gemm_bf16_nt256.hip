@@ -208,17 +208,28 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_bf16_k(NtArgsB p) {
             // per-row partial (sum, sum of squares) of each column half: [wn][256][2] behind the staging strips; every
             // slot has exactly one writer (plain LDS stores, no atomics, nothing to zero)
             float* rowstat = reinterpret_cast<float*>(smb + (buf ^ 1) * BUFB) + 4 * (32 * SLD);
-            static_assert(STAT == 0 || (4 * 32 * SLD + 4 * BT) * 4 <= BUFB, "no room for the row statistics");
+            static_assert(STAT == X_NONE || STAT == X_LNFOLD || (4 * 32 * SLD + 4 * BT) * 4 <= BUFB, "no room for the row statistics");
             const int col = n0 + wn * 128 + ec;
             f32x4 bv0 = {0.f, 0.f, 0.f, 0.f}, bv1 = bv0;
             if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_DROP_RES || EPI == EPI_BIAS_GELU_DROP)
                 if (p.bias) { bv0 = *reinterpret_cast<const f32x4*>(p.bias + col); bv1 = *reinterpret_cast<const f32x4*>(p.bias + col + 4); }
+            f32x4 sv0 = bv0, sv1 = bv0, cv0 = bv0, cv1 = bv0;  // X_LNFOLD: s_n and c_n of the lane's 8 columns
+            if constexpr (STAT == X_LNFOLD) {
+                sv0 = *reinterpret_cast<const f32x4*>(p.gamma + col); sv1 = *reinterpret_cast<const f32x4*>(p.gamma + col + 4);
+                cv0 = *reinterpret_cast<const f32x4*>(p.beta + col); cv1 = *reinterpret_cast<const f32x4*>(p.beta + col + 4);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int64_t off0 = (m0 + wm * 128 + i * 32 + er) * p.N + col;       // row 4 ps + er: + 4 ps N
                 const int64_t rs4 = 4 * (int64_t)p.N;
+                float rr[8], rm[8];                             // X_LNFOLD: rstd and mean of the piece's rows
+                if constexpr (STAT == X_LNFOLD) {
+                    const int64_t r0 = m0 + wm * 128 + i * 32 + er;
+#pragma unroll
+                    for (int ps = 0; ps < 8; ++ps) { rr[ps] = p.rstd[r0 + 4 * ps]; rm[ps] = p.mean[r0 + 4 * ps]; }
+                }
                 MergeWalk mw;
-                if constexpr (STAT == 2) mw.start(m0 + wm * 128 + i * 32 + er, p.mg_F, p.mg_K, 4);
+                if constexpr (STAT == X_STAT_MERGE) mw.start(m0 + wm * 128 + i * 32 + er, p.mg_F, p.mg_K, 4);
                 u32x4 ex[8];                                    // residual / pre-activation of the piece: in flight while it is parked
                 if constexpr (EPI == EPI_BIAS_DROP_RES || EPI == EPI_GELU_BWD) {
                     const bf16_t* src = (EPI == EPI_BIAS_DROP_RES ? p.res : p.aux) + off0;
@@ -234,8 +245,14 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_bf16_k(NtArgsB p) {
 #pragma unroll
                 for (int ps = 0; ps < 8; ++ps) {
                     const int64_t off = off0 + ps * rs4;
-                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + (4 * ps + er) * SLD + ec) + bv0;
-                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + (4 * ps + er) * SLD + ec + 4) + bv1;
+                    f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + (4 * ps + er) * SLD + ec);
+                    f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + (4 * ps + er) * SLD + ec + 4);
+                    if constexpr (STAT == X_LNFOLD) {
+                        const float t = rm[ps] * rr[ps];
+                        v0 = v0 * rr[ps] + (cv0 - sv0 * t); v1 = v1 * rr[ps] + (cv1 - sv1 * t);
+                    } else {
+                        v0 += bv0; v1 += bv1;
+                    }
                     float o8[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
                     float dk[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
                     if constexpr (EPI == EPI_BIAS_DROP_RES || EPI == EPI_BIAS_GELU_DROP || EPI == EPI_GELU_BWD) {
@@ -263,7 +280,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_bf16_k(NtArgsB p) {
                         for (int e = 0; e < 8; ++e) o8[e] = o8[e] * dk[e] * gelu_grad(h[e]);
                     }
                     const u32x4 outv = pack8(o8);
-                    if constexpr (STAT != 0) {                  // statistics of what the next LayerNorm will read: the bf16 values
+                    if constexpr (STAT == X_STAT || STAT == X_STAT_MERGE) {                  // statistics of what the next LayerNorm will read: the bf16 values
                         float q[8];
                         unpack8(outv, q);
                         float s1 = 0.f, s2 = 0.f;
@@ -272,7 +289,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_bf16_k(NtArgsB p) {
                         s1 = group_sum<16>(s1); s2 = group_sum<16>(s2);
                         const int lr = wm * 128 + i * 32 + 4 * ps + er;
                         if ((lane & 15) == 0) { f32x2 st = {s1, s2}; *reinterpret_cast<f32x2*>(rowstat + (wn * BT + lr) * 2) = st; }
-                        if constexpr (STAT == 2) {
+                        if constexpr (STAT == X_STAT_MERGE) {
                             *reinterpret_cast<u32x4*>(p.C + mw.off(p.N) + col) = outv;
                             mw.next();
                         } else {
@@ -285,10 +302,10 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_bf16_k(NtArgsB p) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             }
-            if constexpr (STAT != 0) {
+            if constexpr (STAT == X_STAT || STAT == X_STAT_MERGE) {
                 __syncthreads();
                 int64_t mr = m0 + tid;
-                if constexpr (STAT == 2) { MergeWalk w; w.start(m0 + tid, p.mg_F, p.mg_K, 1); mr = w.mrow(); }
+                if constexpr (STAT == X_STAT_MERGE) { MergeWalk w; w.start(m0 + tid, p.mg_F, p.mg_K, 1); mr = w.mrow(); }
                 atomicAdd(p.stat_sum + mr, rowstat[2 * tid] + rowstat[2 * (BT + tid)]);
                 atomicAdd(p.stat_sq + mr, rowstat[2 * tid + 1] + rowstat[2 * (BT + tid) + 1]);
             }
@@ -301,11 +318,20 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_bf16_k(NtArgsB p) {
 }
 
 template <int PRO>
-int launch(const NtArgsB& a, int epi, int grid, hipStream_t st) {
+int launch(const NtArgsB& a, int epi, int grid, hipStream_t st, bool fold = false) {
     if (a.stat_sum != nullptr) {                                // validated by the caller: PRO_NONE, EPI_BIAS_DROP_RES
         if constexpr (PRO == PRO_NONE) {
             if (a.mg_K > 0) gemm_nt256_bf16_k<PRO_NONE, EPI_BIAS_DROP_RES, 2><<<grid, 256, 0, st>>>(a);
             else gemm_nt256_bf16_k<PRO_NONE, EPI_BIAS_DROP_RES, 1><<<grid, 256, 0, st>>>(a);
+            HWGAT_LAUNCH_CHECK();
+        }
+        return HWGAT_EINVAL;
+    }
+    if (fold) {                                                 // PRO_LN_FOLD: plain loaders, row-affine epilogue
+        if constexpr (PRO == PRO_NONE) {
+            if (epi == EPI_BIAS) gemm_nt256_bf16_k<PRO_NONE, EPI_BIAS, X_LNFOLD><<<grid, 256, 0, st>>>(a);
+            else if (epi == EPI_BIAS_GELU_DROP) gemm_nt256_bf16_k<PRO_NONE, EPI_BIAS_GELU_DROP, X_LNFOLD><<<grid, 256, 0, st>>>(a);
+            else return HWGAT_EINVAL;
             HWGAT_LAUNCH_CHECK();
         }
         return HWGAT_EINVAL;
@@ -330,6 +356,7 @@ int hwgat_launch_nt256_bf16(const NtArgsB& a, int pro, int epi, hipStream_t st) 
     const int grid = (int)(tiles < 256 ? tiles : 256);          // persistent: one block per CU
     switch (pro) {
         case PRO_NONE: return launch<PRO_NONE>(a, epi, grid, st);
+        case PRO_LN_FOLD: return launch<PRO_NONE>(a, epi, grid, st, true);
         case PRO_LN: return launch<PRO_LN>(a, epi, grid, st);
         case PRO_DROP: return launch<PRO_DROP>(a, epi, grid, st);
         default: return HWGAT_EINVAL;

@@ -194,7 +194,7 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt
             float* stg = sm + (buf ^ 1) * ((BM + BN) * LDT) + wave * (32 * SLD);
             const int er = lane / LPR, ec = (lane % LPR) * 4;
             float* rowstat = sm + (buf ^ 1) * ((BM + BN) * LDT) + (C::THREADS / 64) * (32 * SLD);   // [BM][2] behind the staging
-            if constexpr (STAT != 0) {
+            if constexpr (STAT == X_STAT || STAT == X_STAT_MERGE) {
                 static_assert((C::THREADS / 64) * 32 * SLD + 2 * BM <= (BM + BN) * LDT, "no room for the row statistics");
                 for (int q = tid; q < 2 * BM; q += C::THREADS) rowstat[q] = 0.f;
                 __syncthreads();
@@ -205,14 +205,28 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt
                 f32x4 bv = {0.f, 0.f, 0.f, 0.f};
                 if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_DROP_RES || EPI == EPI_BIAS_GELU_DROP)
                     if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + col);
+                f32x4 sv = bv, cv = bv;                         // X_LNFOLD: s_n and c_n of the lane's columns
+                if constexpr (STAT == X_LNFOLD) {
+                    sv = *reinterpret_cast<const f32x4*>(p.gamma + col);
+                    cv = *reinterpret_cast<const f32x4*>(p.beta + col);
+                }
 #pragma unroll
                 for (int i = 0; i < TMW; ++i) {
+                    float rr_[NPS], rm[NPS];                    // X_LNFOLD: rstd and mean of the piece's rows
+                    if constexpr (STAT == X_LNFOLD) {
+#pragma unroll
+                        for (int ps = 0; ps < NPS; ++ps) {
+                            int64_t grow = m0 + wm * (TMW * 32) + i * 32 + ps * RPS + er;
+                            if constexpr (RAGGED) grow = grow < m_last ? grow : m_last;
+                            rr_[ps] = p.rstd[grow]; rm[ps] = p.mean[grow];
+                        }
+                    }
                     // the piece's residual / pre-activation operand: ALL its passes are requested before the piece is
                     // parked, so NPS loads per lane are in flight together (they used to be issued pass by pass, two
                     // at a time, each paying an HBM round trip: the GELU-backward launch, whose largest stream this
                     // is, ran at 99 TFLOP/s against 130 for the plain product)
                     MergeWalk mw;
-                    if constexpr (STAT == 2) mw.start(m0 + wm * (TMW * 32) + i * 32 + er, p.mg_F, p.mg_K, RPS);
+                    if constexpr (STAT == X_STAT_MERGE) mw.start(m0 + wm * (TMW * 32) + i * 32 + er, p.mg_F, p.mg_K, RPS);
                     f32x4 ex[NPS];
                     if constexpr (EPI == EPI_BIAS_DROP_RES || EPI == EPI_GELU_BWD) {
                         const float* src = EPI == EPI_BIAS_DROP_RES ? p.res : p.aux;
@@ -236,7 +250,9 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt
                         const int64_t grow = m0 + wm * (TMW * 32) + i * 32 + rr;
                         if constexpr (RAGGED) { if (grow > m_last) continue; }
                         const int64_t off = grow * p.N + col;       // natural layout: residual, dropout hash
-                        f32x4 v = *reinterpret_cast<const f32x4*>(stg + rr * SLD + ec) + bv;
+                        f32x4 v = *reinterpret_cast<const f32x4*>(stg + rr * SLD + ec);
+                        if constexpr (STAT == X_LNFOLD) v = v * rr_[ps] + (cv - sv * (rm[ps] * rr_[ps]));
+                        else v += bv;
                         f32x4 dk = {1.f, 1.f, 1.f, 1.f};
                         if constexpr (EPI == EPI_BIAS_DROP_RES || EPI == EPI_BIAS_GELU_DROP || EPI == EPI_GELU_BWD) {
                             if (epi_th) dk = drop_keep4(p.epi_seed, (uint64_t)(off + (RAGGED ? p.row0 * p.N : 0)), epi_th, epi_sc);
@@ -252,7 +268,7 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt
                             v.x *= dk.x * gelu_grad(h.x); v.y *= dk.y * gelu_grad(h.y);
                             v.z *= dk.z * gelu_grad(h.z); v.w *= dk.w * gelu_grad(h.w);
                         }
-                        if constexpr (STAT != 0) {
+                        if constexpr (STAT == X_STAT || STAT == X_STAT_MERGE) {
                             float s1 = (v.x + v.y) + (v.z + v.w), s2 = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
                             s1 = group_sum<LPR>(s1); s2 = group_sum<LPR>(s2);
                             if ((lane % LPR) == 0) {
@@ -260,7 +276,7 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt
                                 atomicAdd(rowstat + 2 * lr, s1);
                                 atomicAdd(rowstat + 2 * lr + 1, s2);
                             }
-                            if constexpr (STAT == 2) {
+                            if constexpr (STAT == X_STAT_MERGE) {
                                 *reinterpret_cast<f32x4*>(p.C + mw.off(p.N) + col) = v;
                                 mw.next();
                             } else {
@@ -274,11 +290,11 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt
                     __builtin_amdgcn_wave_barrier();
                 }
             }
-            if constexpr (STAT != 0) {
+            if constexpr (STAT == X_STAT || STAT == X_STAT_MERGE) {
                 __syncthreads();
                 for (int q = tid; q < BM; q += C::THREADS) {            // consecutive rows -> coalesced global atomics
                     int64_t mr = m0 + q;
-                    if constexpr (STAT == 2) { MergeWalk w; w.start(m0 + q, p.mg_F, p.mg_K, 1); mr = w.mrow(); }
+                    if constexpr (STAT == X_STAT_MERGE) { MergeWalk w; w.start(m0 + q, p.mg_F, p.mg_K, 1); mr = w.mrow(); }
                     atomicAdd(p.stat_sum + mr, rowstat[2 * q]);
                     atomicAdd(p.stat_sq + mr, rowstat[2 * q + 1]);
                 }
@@ -471,9 +487,18 @@ __global__ void transpose_k(const float* __restrict__ in, float* __restrict__ ou
 }
 
 template <int PRO, typename C, bool RAGGED = false>
-int launch_nt(const NtArgs& a, int epi, hipStream_t st) {
+int launch_nt(const NtArgs& a, int epi, hipStream_t st, bool fold = false) {
     const int64_t tiles = ((a.M + C::BM - 1) / C::BM) * (a.N / C::BN);
     const int grid = (int)(tiles < C::SLOTS ? tiles : C::SLOTS);      // persistent over tiles
+    if (fold) {                                                         // PRO_LN_FOLD: plain loaders, row-affine epilogue
+        if constexpr (PRO == PRO_NONE) {
+            if (epi == EPI_BIAS) gemm_nt_k<PRO_NONE, EPI_BIAS, C, RAGGED, X_LNFOLD><<<grid, C::THREADS, 0, st>>>(a);
+            else if (epi == EPI_BIAS_GELU_DROP) gemm_nt_k<PRO_NONE, EPI_BIAS_GELU_DROP, C, RAGGED, X_LNFOLD><<<grid, C::THREADS, 0, st>>>(a);
+            else return HWGAT_EINVAL;
+            HWGAT_LAUNCH_CHECK();
+        }
+        return HWGAT_EINVAL;
+    }
     if (a.stat_sum != nullptr) {                                        // validated by the caller: PRO_NONE, EPI_BIAS_DROP_RES, M % 128 == 0
         if constexpr (PRO == PRO_NONE && !RAGGED) {
             if (a.mg_K > 0) gemm_nt_k<PRO_NONE, EPI_BIAS_DROP_RES, C, false, 2><<<grid, C::THREADS, 0, st>>>(a);
@@ -560,7 +585,11 @@ extern "C" int hwgat_linear_nt_f32_ex(const float* A, const float* W, const floa
                                       void* stream) {
     if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) return HWGAT_EINVAL;
     if (N % 128 || K % 32 || ((M + 127) / 128) * (int64_t)(N / 128) > 0x7fffffff) return HWGAT_ESHAPE;   // any M
-    if (pro == PRO_LN && (!mean || !rstd || !gamma || !beta)) return HWGAT_EINVAL;
+    if ((pro == PRO_LN || pro == PRO_LN_FOLD) && (!mean || !rstd || !gamma || !beta)) return HWGAT_EINVAL;
+    if (pro == PRO_LN_FOLD) {                                      // gamma = s[N], beta = c[N] of hwgat_ln_fold; whole tiles
+        if (epi != EPI_BIAS && epi != EPI_BIAS_GELU_DROP) return HWGAT_EINVAL;
+        if (M % 128) return HWGAT_ESHAPE;
+    }
     if (epi == EPI_BIAS_DROP_RES && !res) return HWGAT_EINVAL;
     if (epi == EPI_BIAS_GELU_DROP && !C2) return HWGAT_EINVAL;
     if (epi == EPI_GELU_BWD && !aux) return HWGAT_EINVAL;
@@ -616,6 +645,7 @@ extern "C" int hwgat_linear_nt_f32_ex(const float* A, const float* W, const floa
         const NtArgs t = nt_rows(a, m256, M - m256);      // 128 rows left: the RAGGED instantiation hashes dropout
         switch (pro) {                                     // masks with the global row index (row0)
             case PRO_NONE: return launch_nt<PRO_NONE, NtSmall, true>(t, epi, st);
+            case PRO_LN_FOLD: return launch_nt<PRO_NONE, NtSmall, true>(t, epi, st, true);
             case PRO_LN: return launch_nt<PRO_LN, NtSmall, true>(t, epi, st);
             case PRO_DROP: return launch_nt<PRO_DROP, NtSmall, true>(t, epi, st);
             default: return HWGAT_EINVAL;
@@ -627,6 +657,7 @@ extern "C" int hwgat_linear_nt_f32_ex(const float* A, const float* W, const floa
 #define NT_GO(P) return big ? launch_nt<P, NtBig>(a, epi, st) : (k16 ? launch_nt<P, NtK16>(a, epi, st) : launch_nt<P, NtSmall>(a, epi, st))
     switch (pro) {
         case PRO_NONE: NT_GO(PRO_NONE);
+        case PRO_LN_FOLD: return k16 ? launch_nt<PRO_NONE, NtK16>(a, epi, st, true) : launch_nt<PRO_NONE, NtSmall>(a, epi, st, true);
         case PRO_LN: NT_GO(PRO_LN);
         case PRO_DROP: NT_GO(PRO_DROP);
         default: return HWGAT_EINVAL;

@@ -53,7 +53,8 @@ __device__ __forceinline__ void pin() {
 // STAT (EPI_BIAS_DROP_RES only): row sums / sums of squares of the output for the next LayerNorm and the optional
 // TemporalMerging store, exactly as in gemm_nt_k (see NtArgs in gemm_f32.h)
 // (STAT: 0 = plain epilogue, 1 = + row statistics, 2 = + row statistics and the merged store: separate instantiations,
-//  because the merged store's index arithmetic would otherwise sit, as a branch per pass, in every epilogue)
+//  because the merged store's index arithmetic would otherwise sit, as a branch per pass, in every epilogue;
+//  3 = X_LNFOLD, the row-affine epilogue of a folded LayerNorm -- fused_ops.h)
 template <int PRO, int EPI, int STAT = 0>
 __global__ __launch_bounds__(256, 1) void gemm_nt256_k(NtArgs p) {
     __shared__ __attribute__((aligned(16))) float sm[2 * BUF];
@@ -217,17 +218,28 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_k(NtArgs p) {
             // per-row partial (sum, sum of squares) of each column half: [wn][256][2] behind the staging strips; every
             // slot has exactly one writer (plain LDS stores, no atomics, nothing to zero)
             float* rowstat = sm + (buf ^ 1) * BUF + 4 * (32 * SLD);
-            static_assert(STAT == 0 || 4 * 32 * SLD + 4 * BT <= BUF, "no room for the row statistics");
+            static_assert(STAT == X_NONE || STAT == X_LNFOLD || 4 * 32 * SLD + 4 * BT <= BUF, "no room for the row statistics");
             const int col = n0 + wn * 128 + ec;
             f32x4 bv = {0.f, 0.f, 0.f, 0.f};
             if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_DROP_RES || EPI == EPI_BIAS_GELU_DROP)
                 if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + col);
+            f32x4 sv = bv, cv = bv;                             // X_LNFOLD: s_n and c_n of the lane's columns
+            if constexpr (STAT == X_LNFOLD) {
+                sv = *reinterpret_cast<const f32x4*>(p.gamma + col);
+                cv = *reinterpret_cast<const f32x4*>(p.beta + col);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int64_t off0 = (m0 + wm * 128 + i * 32 + er) * p.N + col;       // row 2 ps + er: + 2 ps N
+                float rr[16], rm[16];                           // X_LNFOLD: rstd and mean * rstd of the piece's rows
+                if constexpr (STAT == X_LNFOLD) {
+                    const int64_t r0 = m0 + wm * 128 + i * 32 + er;
+#pragma unroll
+                    for (int ps = 0; ps < 16; ++ps) { rr[ps] = p.rstd[r0 + 2 * ps]; rm[ps] = p.mean[r0 + 2 * ps]; }
+                }
                 const int64_t rs2 = 2 * (int64_t)p.N;
                 MergeWalk mw;
-                if constexpr (STAT == 2) mw.start(m0 + wm * 128 + i * 32 + er, p.mg_F, p.mg_K, 2);
+                if constexpr (STAT == X_STAT_MERGE) mw.start(m0 + wm * 128 + i * 32 + er, p.mg_F, p.mg_K, 2);
                 // operands of this piece (residual / pre-activation): in flight while the piece is parked
                 f32x4 ex[16];
                 if constexpr (EPI == EPI_BIAS_DROP_RES || EPI == EPI_GELU_BWD) {
@@ -244,7 +256,9 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_k(NtArgs p) {
 #pragma unroll
                 for (int ps = 0; ps < 16; ++ps) {
                     const int64_t off = off0 + ps * rs2;
-                    f32x4 v = *reinterpret_cast<const f32x4*>(stg + (2 * ps + er) * SLD + ec) + bv;
+                    f32x4 v = *reinterpret_cast<const f32x4*>(stg + (2 * ps + er) * SLD + ec);
+                    if constexpr (STAT == X_LNFOLD) v = v * rr[ps] + (cv - sv * (rm[ps] * rr[ps]));
+                    else v += bv;
                     f32x4 dk = {1.f, 1.f, 1.f, 1.f};
                     if constexpr (EPI == EPI_BIAS_DROP_RES || EPI == EPI_BIAS_GELU_DROP || EPI == EPI_GELU_BWD) {
                         dk = drop_keep4(p.epi_seed, (uint64_t)off, epi_th, epi_sc);
@@ -260,12 +274,12 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_k(NtArgs p) {
                         v.x *= dk.x * gelu_grad(h.x); v.y *= dk.y * gelu_grad(h.y);
                         v.z *= dk.z * gelu_grad(h.z); v.w *= dk.w * gelu_grad(h.w);
                     }
-                    if constexpr (STAT != 0) {
+                    if constexpr (STAT == X_STAT || STAT == X_STAT_MERGE) {
                         float s1 = (v.x + v.y) + (v.z + v.w), s2 = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
                         s1 = group_sum<32>(s1); s2 = group_sum<32>(s2);
                         const int lr = wm * 128 + i * 32 + 2 * ps + er;
                         if ((lane & 31) == 0) { f32x2 st = {s1, s2}; *reinterpret_cast<f32x2*>(rowstat + (wn * BT + lr) * 2) = st; }
-                        if constexpr (STAT == 2) {
+                        if constexpr (STAT == X_STAT_MERGE) {
                             *reinterpret_cast<f32x4*>(p.C + mw.off(p.N) + col) = v;
                             mw.next();
                         } else {
@@ -278,10 +292,10 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_k(NtArgs p) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             }
-            if constexpr (STAT != 0) {
+            if constexpr (STAT == X_STAT || STAT == X_STAT_MERGE) {
                 __syncthreads();
                 int64_t mr = m0 + tid;                          // 256 consecutive rows -> coalesced global atomics
-                if constexpr (STAT == 2) { MergeWalk w; w.start(m0 + tid, p.mg_F, p.mg_K, 1); mr = w.mrow(); }
+                if constexpr (STAT == X_STAT_MERGE) { MergeWalk w; w.start(m0 + tid, p.mg_F, p.mg_K, 1); mr = w.mrow(); }
                 atomicAdd(p.stat_sum + mr, rowstat[2 * tid] + rowstat[2 * (BT + tid)]);
                 atomicAdd(p.stat_sq + mr, rowstat[2 * tid + 1] + rowstat[2 * (BT + tid) + 1]);
             }
@@ -294,11 +308,20 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_k(NtArgs p) {
 }
 
 template <int PRO>
-int launch(const NtArgs& a, int epi, int grid, hipStream_t st) {
+int launch(const NtArgs& a, int epi, int grid, hipStream_t st, bool fold = false) {
     if (a.stat_sum != nullptr) {                                // validated by the caller: PRO_NONE, EPI_BIAS_DROP_RES
         if constexpr (PRO == PRO_NONE) {
             if (a.mg_K > 0) gemm_nt256_k<PRO_NONE, EPI_BIAS_DROP_RES, 2><<<grid, 256, 0, st>>>(a);
             else gemm_nt256_k<PRO_NONE, EPI_BIAS_DROP_RES, 1><<<grid, 256, 0, st>>>(a);
+            HWGAT_LAUNCH_CHECK();
+        }
+        return HWGAT_EINVAL;
+    }
+    if (fold) {                                                 // PRO_LN_FOLD: plain loaders, row-affine epilogue
+        if constexpr (PRO == PRO_NONE) {
+            if (epi == EPI_BIAS) gemm_nt256_k<PRO_NONE, EPI_BIAS, X_LNFOLD><<<grid, 256, 0, st>>>(a);
+            else if (epi == EPI_BIAS_GELU_DROP) gemm_nt256_k<PRO_NONE, EPI_BIAS_GELU_DROP, X_LNFOLD><<<grid, 256, 0, st>>>(a);
+            else return HWGAT_EINVAL;
             HWGAT_LAUNCH_CHECK();
         }
         return HWGAT_EINVAL;
@@ -323,6 +346,7 @@ int hwgat_launch_nt256(const NtArgs& a, int pro, int epi, hipStream_t st) {
     const int grid = (int)(tiles < 256 ? tiles : 256);          // persistent: one block per CU
     switch (pro) {
         case PRO_NONE: return launch<PRO_NONE>(a, epi, grid, st);
+        case PRO_LN_FOLD: return launch<PRO_NONE>(a, epi, grid, st, true);
         case PRO_LN: return launch<PRO_LN>(a, epi, grid, st);
         case PRO_DROP: return launch<PRO_DROP>(a, epi, grid, st);
         default: return HWGAT_EINVAL;

@@ -310,7 +310,43 @@ __global__ void ln_finalize_k(float* __restrict__ sum_mean, float* __restrict__ 
     }
 }
 
+// LayerNorm folded into the linear that consumes it (PRO_LN_FOLD, fused_ops.h):
+//   LN(x) W^T + b = rstd_m (x (W o gamma)^T - mean_m s) + c,   s_n = sum_k W'[n,k],  c_n = b_n + sum_k beta_k W[n,k]
+// One wave per output row n: W' = W o gamma stored in the activation dtype, s summed over the STORED (rounded)
+// values so that the mean term cancels exactly against the product the MFMA forms, c from the fp32 weights.
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fold_k(const float* __restrict__ W, const float* __restrict__ bias,
+                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                 T* __restrict__ Wf, float* __restrict__ s, float* __restrict__ c, int N, int K) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= N) return;
+    const float* w = W + (int64_t)n * K;
+    T* wf = Wf + (int64_t)n * K;
+    float ss = 0.f, cc = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const float wv = w[k];
+        const T r = (T)(wv * gamma[k]);
+        wf[k] = r;
+        ss += (float)r;
+        cc = fmaf(beta[k], wv, cc);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { ss += __shfl_xor(ss, o); cc += __shfl_xor(cc, o); }
+    if (lane == 0) { s[n] = ss; c[n] = cc + (bias ? bias[n] : 0.f); }
+}
+
 }  // namespace
+
+extern "C" int hwgat_ln_fold(const float* W, const float* bias, const float* gamma, const float* beta, int N, int K,
+                             void* Wf, float* s, float* c, int dtype, void* stream) {
+    if (!W || !gamma || !beta || !Wf || !s || !c || N <= 0 || K <= 0) return HWGAT_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = (N + 3) / 4;
+    if (dtype == HWGAT_F32) ln_fold_k<float><<<grid, 256, 0, st>>>(W, bias, gamma, beta, (float*)Wf, s, c, N, K);
+    else if (dtype == HWGAT_BF16) ln_fold_k<bf16_t><<<grid, 256, 0, st>>>(W, bias, gamma, beta, (bf16_t*)Wf, s, c, N, K);
+    else return HWGAT_EINVAL;
+    HWGAT_LAUNCH_CHECK();
+}
 
 extern "C" int hwgat_ln_finalize(float* sum_mean, float* sq_rstd, int64_t n, int d, void* stream) {
     if (!sum_mean || !sq_rstd || n <= 0 || d <= 0) return HWGAT_EINVAL;

@@ -4,6 +4,8 @@ Every function here calls straight into libhwgat_hip.so through `_lib.call`;
 nothing falls back to torch arithmetic.  All activations are in the natural
 token order (B, F, K, d).
 """
+import os
+
 import torch
 
 from . import _lib
@@ -324,7 +326,11 @@ def ln_mean_pool(x, gamma, beta):
 
 
 # ---------------------------------------------------------------- fp32 MFMA linears
-PRO_NONE, PRO_LN, PRO_DROP = 0, 1, 2
+PRO_NONE, PRO_LN, PRO_DROP, PRO_LN_FOLD = 0, 1, 2, 3
+# LayerNorm -> Linear pairs (norm1 -> qkv, norm2 -> fc1) run with the normalisation folded into the weights and
+# the GEMM epilogue (hwgat_ln_fold + pro 3) when the token count is whole tiles; HWGAT_LN_FOLD=0 keeps the
+# in-kernel normalising loader (pro 1) everywhere.
+LN_FOLD = os.environ.get("HWGAT_LN_FOLD", "1") != "0"
 EPI_BIAS, EPI_BIAS_DROP_RES, EPI_BIAS_GELU_DROP, EPI_GELU_BWD, EPI_NONE = 0, 1, 2, 3, 4
 
 
@@ -365,12 +371,35 @@ def linear_nt(A, W, bias=None, *, pro=PRO_NONE, ln=None, pro_seed=0, pro_p=0.0, 
     C = out if out is not None else torch.empty(*A.shape[:-1], N, device=A.device, dtype=A.dtype)
     C2 = torch.empty_like(C) if epi == EPI_BIAS_GELU_DROP else None
     mean = rstd = gamma = beta = None
-    if pro == PRO_LN:
+    if pro in (PRO_LN, PRO_LN_FOLD):
         mean, rstd, gamma, beta = ln
     call("hwgat_linear_nt_f32" if A.dtype == torch.float32 else "hwgat_linear_nt_bf16", ptr(A), ptr(W), ptr(bias), ptr(C), M, N, K, pro, ptr(mean), ptr(rstd),
          ptr(gamma), ptr(beta), pro_seed & 0xFFFFFFFF, float(pro_p), epi, ptr(res), ptr(C2), ptr(aux),
          epi_seed & 0xFFFFFFFF, float(epi_p), stream())
     return (C, C2) if C2 is not None else C
+
+
+def ln_fold(W, bias, gamma, beta, dtype):
+    """(W o gamma in `dtype`, s, c) for pro = PRO_LN_FOLD from the fp32 master weights (hwgat_ln_fold)"""
+    N, K = W.shape
+    Wf = torch.empty(N, K, device=W.device, dtype=dtype)
+    sc = torch.empty(2, N, device=W.device, dtype=torch.float32)
+    call("hwgat_ln_fold", ptr(W), ptr(bias), ptr(gamma), ptr(beta), N, K, ptr(Wf), ptr(sc[0]), ptr(sc[1]),
+         0 if dtype == torch.float32 else 1, stream())
+    return Wf, sc[0], sc[1]
+
+
+def linear_nt_ln(A, W, bias, ln, *, epi=EPI_BIAS, epi_seed=0, epi_p=0.0, out=None):
+    """LN(A) . W^T + bias with the epilogue `epi` (EPI_BIAS or EPI_BIAS_GELU_DROP); W, bias are the fp32 master
+    parameters, ln = (mean, rstd, gamma, beta).  Whole-tile token counts take the folded form (no per-element
+    normalisation in the GEMM's load path), anything else the normalising loader."""
+    mean, rstd, gamma, beta = ln
+    M = A.numel() // A.shape[-1]
+    if LN_FOLD and M % 128 == 0:
+        Wf, s, c = ln_fold(W, bias, gamma, beta, A.dtype)
+        return linear_nt(A, Wf, None, pro=PRO_LN_FOLD, ln=(mean, rstd, s, c), epi=epi, epi_seed=epi_seed, epi_p=epi_p, out=out)
+    Wc = W if W.dtype == A.dtype else W.to(A.dtype)
+    return linear_nt(A, Wc, bias, pro=PRO_LN, ln=ln, epi=epi, epi_seed=epi_seed, epi_p=epi_p, out=out)
 
 
 def linear_tn(A, Bm, dW, db=None, *, pro_seed=0, pro_p=0.0, ln=None):

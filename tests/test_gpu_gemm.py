@@ -245,7 +245,9 @@ def test_bf16_nt_epilogues(p):
     assert rel_err(got.float().cpu(), _b((Ab.cpu().double() * maskA).float()).double() @ Wb.cpu().double().t()) < BT
 
 
-@pytest.mark.parametrize("M,N,K,p", [(512, 128, 128, 0.0), (4096, 384, 128, 0.0), (32 * 301, 256, 512, 0.1), (65536, 128, 256, 0.0)])
+# the last four: gemm_tn256_bf16_k (dW at least 256 x 256, M % 64 == 0) -- one split of two stages up to many splits
+@pytest.mark.parametrize("M,N,K,p", [(512, 128, 128, 0.0), (4096, 384, 128, 0.0), (32 * 301, 256, 512, 0.1), (65536, 128, 256, 0.0),
+                                     (64, 256, 256, 0.1), (64 * 301, 256, 512, 0.1), (163840, 512, 256, 0.0), (64 * 37, 768, 256, 0.1)])
 def test_bf16_tn_weight_and_bias_grad(M, N, K, p):
     g = torch.Generator().manual_seed(M + K)
     dY, X = _b(torch.randn(M, N, generator=g)), _b(torch.randn(M, K, generator=g))
@@ -419,3 +421,36 @@ def test_bf16_nt256_persistent_tile_loop_every_prologue_and_epilogue(M, N, K, pr
     worst = max(rel_err(got[rows][i * 128:(i + 1) * 128].float().cpu(), ref[i * 128:(i + 1) * 128]) for i in range(len(rows) // 128))
     assert worst < 2 * BT, worst
     assert bool(torch.isfinite(got.float()).all())
+
+
+# ---- LayerNorm folded into the weights and the epilogue (hwgat_ln_fold + pro 3): the form norm1 -> qkv and norm2 -> fc1
+# take on whole-tile token counts.  Rows with a mean of three standard deviations exercise the cancellation
+# rstd (acc - mean s); every NT kernel family is hit: 128x128 (N = 384), 256x256 + its 128-row remainder launch.
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("M,N,K", [(128 * 5, 384, 128), (256 * 3 + 128, 512, 256), (256 * 40, 256, 512)])
+def test_layernorm_folded_into_weights_and_epilogue(M, N, K, dtype):
+    dt = torch.float32 if dtype == "f32" else torch.bfloat16
+    g = torch.Generator().manual_seed(M + N + K)
+    A = (torch.randn(M, K, generator=g) * (0.5 + torch.rand(M, 1, generator=g)) + 3.0 * torch.randn(M, 1, generator=g)).to(dt)
+    W, b = torch.randn(N, K, generator=g) * 0.1, torch.randn(N, generator=g)
+    gamma, beta = 1.0 + 0.3 * torch.randn(K, generator=g), 0.3 * torch.randn(K, generator=g)
+    Ad = A.to(DEV)
+    ln = HF.ln_stats(Ad, gamma.to(DEV), beta.to(DEV)) + (gamma.to(DEV), beta.to(DEV))
+    Wf, s, c = HF.ln_fold(W.to(DEV), b.to(DEV), gamma.to(DEV), beta.to(DEV), dt)
+    assert rel_err(Wf.float().cpu(), W.double() * gamma.double()) < (1e-6 if dtype == "f32" else 4e-3)
+    assert rel_err(s.cpu(), Wf.float().cpu().double().sum(1)) < 1e-5          # of the STORED values
+    assert rel_err(c.cpu(), b.double() + W.double() @ beta.double()) < 1e-5
+    xn = torch.nn.functional.layer_norm(A.double(), (K,), gamma.double(), beta.double())
+    lin = xn @ W.double().t() + b.double()
+    tol = 3e-5 if dtype == "f32" else 1e-2
+    assert HF.LN_FOLD
+    got = HF.linear_nt_ln(Ad, W.to(DEV), b.to(DEV), ln)
+    assert rel_err(got.float().cpu(), lin) < tol
+    p = 0.1
+    u, h1 = HF.linear_nt_ln(Ad, W.to(DEV), b.to(DEV), ln, epi=HF.EPI_BIAS_GELU_DROP, epi_seed=1234, epi_p=p)
+    mask = HF.dropout_mask((M, N), 1234, p, DEV).cpu().double()
+    assert rel_err(h1.float().cpu(), lin) < tol
+    assert rel_err(u.float().cpu(), torch.nn.functional.gelu(h1.float().cpu().double()) * mask) < (tol if dtype == "f32" else 6e-3)
+    # and it is the same function as the normalising loader (pro 1) up to rounding
+    old = HF.linear_nt(Ad, W.to(DEV).to(dt), b.to(DEV), pro=HF.PRO_LN, ln=ln)
+    assert rel_err(got.float().cpu(), old.float().cpu().double()) < (3e-5 if dtype == "f32" else 1.5e-2)

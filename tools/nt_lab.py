@@ -66,11 +66,27 @@ for i in stages:
             ("fc2   +row statistics     ", M, d, 2 * d, lambda: HF.linear_nt(u2, w2, b1, epi=HF.EPI_BIAS_DROP_RES, res=res, epi_seed=3, epi_p=.1, stats=True)),
             ("fc2   +statistics, merged ", M, d, 2 * d, lambda: HF.linear_nt(u2, w2, b1, epi=HF.EPI_BIAS_DROP_RES, res=res, epi_seed=3, epi_p=.1, stats=True, merge=(T >> i, K))),
         ]
+    if os.environ.get("NT_LAB_ABLATE") == "1":     # what each prologue / epilogue costs: the same shapes with pieces removed
+        cases += [
+            ("qkv   (no LN) bias        ", M, 3 * d, d, lambda: HF.linear_nt(x, w_qkv, b3, out=o3)),
+            ("fc1   LN -> bias only     ", M, 2 * d, d, lambda: HF.linear_nt(x, w1, b2, pro=HF.PRO_LN, ln=ln, out=o2)),
+            ("fc1   (no LN) gelu+drop   ", M, 2 * d, d, lambda: HF.linear_nt(x, w1, b2, epi=HF.EPI_BIAS_GELU_DROP, epi_seed=2, epi_p=.1, out=o2)),
+            ("fc1   (no LN) gelu, p=0   ", M, 2 * d, d, lambda: HF.linear_nt(x, w1, b2, epi=HF.EPI_BIAS_GELU_DROP, epi_seed=2, epi_p=0., out=o2)),
+            ("fc1   (no LN) bias only   ", M, 2 * d, d, lambda: HF.linear_nt(x, w1, b2, out=o2)),
+            ("d_h1  (no drop) gelu-bwd  ", M, 2 * d, d, lambda: HF.linear_nt(x, w2_t, None, epi=HF.EPI_GELU_BWD, aux=aux, epi_seed=2, epi_p=.1, out=o2)),
+            ("d_h1  drop -> plain       ", M, 2 * d, d, lambda: HF.linear_nt(x, w2_t, None, pro=HF.PRO_DROP, pro_seed=3, pro_p=.1, epi=HF.EPI_NONE, out=o2)),
+            ("d_h1  (no drop) plain     ", M, 2 * d, d, lambda: HF.linear_nt(x, w2_t, None, epi=HF.EPI_NONE, out=o2)),
+            ("fc2   bias+res, p=0       ", M, d, 2 * d, lambda: HF.linear_nt(u2, w2, b1, epi=HF.EPI_BIAS_DROP_RES, res=res, epi_seed=3, epi_p=0., out=o1)),
+        ]
     for name, m, n, k, fn in cases:
         t = bench(fn)
         fl = 2.0 * m * n * k
-        if "statistics" not in name:
+        extra = "statistics" in name or "(no" in name or "only" in name or "p=0" in name or name.startswith("d_h1  drop -> plain")
+        if not extra:
             total += t * depth
+        if extra and "statistics" not in name:
+            print(f"stage {i} d={d:4d} {name} M={m} N={n:4d} K={k:4d}: {t * 1e6:8.1f} us  {fl / t / 1e12:6.1f} TF   (ablation)", flush=True)
+            continue
         if "statistics" in name:
             print(f"stage {i} d={d:4d} {name} M={m} N={n:4d} K={k:4d}: {t * 1e6:8.1f} us  {fl / t / 1e12:6.1f} TF   (incl. zero-fill + finalize)", flush=True)
             continue

@@ -24,8 +24,9 @@ def bench(fn, n=8):
     return e0.elapsed_time(e1) / n * 1e-3
 
 
+plain = os.environ.get("TN_LAB_PLAIN") == "1"               # no prologue at all: the bare kernel
 total = 0.0
-for i in (0, 1, 2):
+for i in [int(a) for a in os.environ.get("TN_LAB_STAGES", "0,1,2").split(",")]:
     d = 128 << i
     M = B * (T >> i) * K
     depth = (2, 2, 4)[i]
@@ -39,7 +40,7 @@ for i in (0, 1, 2):
                             ("dW1    LN(y)  ", x2, x1, dict(ln=ln)), ("dW2    drop(dy)", x1, x2, dict(pro_seed=3, pro_p=.1))):
         N, Kd = A.shape[1], Bm.shape[1]
         dW, db = torch.zeros(N, Kd, device=dev), torch.zeros(N, device=dev)
-        t = bench(lambda: HF.linear_tn(A, Bm, dW, db, **kw))
+        t = bench(lambda: HF.linear_tn(A, Bm, dW, db, **({} if plain else kw)))
         fl = 2.0 * M * N * Kd
         total += t * depth
         print(f"stage {i} d={d:4d} {name} M={M} N={N:4d} K={Kd:4d}: {t * 1e6:8.1f} us  {fl / t / 1e12:6.1f} TF  "
