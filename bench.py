@@ -407,9 +407,11 @@ def main():
             fname = "r01k_sibling_attn_pmc_traffic.json" if (hgate or wgate) else "r02_attn_pmc_traffic.json"
             with open(os.path.join(ROOT, "profiles", fname)) as fh:
                 pmc = json.load(fh)
+            if args.dtype == "bf16":
+                pmc = pmc.get("bf16", {})                             # the bf16 passes (config 3 shape)
             for name in kern:
                 rec = pmc.get(name + "_1seg", pmc.get(name))          # band fwd: the shipped 1-segment geometry
-                if rec and rec.get("E_bytes", pmc.get("E_bytes")) == E * itemsize and args.dtype == "f32":
+                if rec and rec.get("E_bytes", pmc.get("E_bytes")) == E * itemsize:
                     kern[name]["traffic"] = rec["traffic_bytes_per_launch"]
         except (OSError, KeyError):
             pass
