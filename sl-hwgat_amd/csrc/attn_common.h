@@ -11,6 +11,7 @@ template <int HD> __device__ __forceinline__ constexpr float qk_scale() {
 }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 // 16-byte raw chunk -> floats written to LDS (optionally scaled)
 template <typename T> struct chunk;
@@ -114,6 +115,103 @@ __device__ __forceinline__ void tile_ay(const float (&a)[16], const float* Y, in
         for (int nt = 0; nt < NT; ++nt)
             acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], y[nt], acc[nt], 0, 0, 0);
     }
+}
+
+// ---------------------------------------------------------------- bf16 storage: the same products on
+// v_mfma_f32_32x32x16_bf16.  With fp32 MFMAs a (window, head) unit of head_dim 64 costs 64 + 32 NT matrix
+// instructions of 64 cycles each whatever the storage type, so halving the bytes (bf16 activations) halved the
+// fraction of the HBM roof these kernels reach (0.49 / 0.45 forward / backward on config 3).  bf16 tiles keep the raw
+// 16-byte chunks in LDS (no expansion to fp32), and every 32x32xHD product is HD / 16 instructions of 32 cycles.
+// Softmax, masks, threshold and all accumulation stay fp32; P and dS are rounded to bf16 only as MFMA operands
+// (what torch.autocast does with the softmax output in front of its bf16 matmul).
+template <typename T> struct tile_of;                  // element type of the LDS tiles, row padding, is Q stored pre-scaled
+template <> struct tile_of<float> { using E = float; static constexpr int PAD = 4; static constexpr bool QSCALED = true; };
+template <> struct tile_of<bf16_t> { using E = bf16_t; static constexpr int PAD = 8; static constexpr bool QSCALED = false; };
+
+__device__ __forceinline__ void raw_to_lds(float* dst, u32x4 raw, float s, float) { chunk<float>::to_lds(dst, raw, s); }
+__device__ __forceinline__ void raw_to_lds(bf16_t* dst, u32x4 raw, float, bf16_t) { *reinterpret_cast<u32x4*>(dst) = raw; }
+
+// four consecutive scratch elements (8-byte aligned fp32 pairs / 4-byte aligned bf16 pairs)
+__device__ __forceinline__ void put4(float* dst, const float* v) {
+    f32x2 a = {v[0], v[1]}, b = {v[2], v[3]};
+    reinterpret_cast<f32x2*>(dst)[0] = a; reinterpret_cast<f32x2*>(dst)[1] = b;
+}
+__device__ __forceinline__ void put4(bf16_t* dst, const float* v) {
+    bf16x2 a = {(bf16_t)v[0], (bf16_t)v[1]}, b = {(bf16_t)v[2], (bf16_t)v[3]};
+    reinterpret_cast<bf16x2*>(dst)[0] = a; reinterpret_cast<bf16x2*>(dst)[1] = b;
+}
+
+__device__ __forceinline__ bf16x8 pack_bf16x8(const float* v) {
+    bf16x8 f = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3], (bf16_t)v[4], (bf16_t)v[5], (bf16_t)v[6], (bf16_t)v[7]};
+    return f;
+}
+
+// D(32x32) = X Y^T for two row-per-lane bf16 tiles [32][LDB]; same result layout as the fp32 form
+template <int HD, int LDB>
+__device__ __forceinline__ f32x16 tile_xyT(const bf16_t* X, const bf16_t* Y, int lq, int hh) {
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const bf16_t* xr = X + lq * LDB + 8 * hh;
+    const bf16_t* yr = Y + lq * LDB + 8 * hh;
+#pragma unroll
+    for (int m = 0; m < HD / 16; ++m) {
+        const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xr + 16 * m);
+        const bf16x8 yf = *reinterpret_cast<const bf16x8*>(yr + 16 * m);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, yf, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+// the NT consecutive elements a lane holds of one row of the B-side matrix (V, K, Q or dO): raw bf16 pairs
+template <int NT> struct brow {
+    static constexpr int W = NT >= 2 ? NT / 2 : 1;
+    uint32_t w[W];
+    __device__ __forceinline__ void load(const bf16_t* p) {
+        if constexpr (NT == 1) w[0] = *reinterpret_cast<const uint16_t*>(p);
+        else if constexpr (NT == 2) w[0] = *reinterpret_cast<const uint32_t*>(p);
+        else { const u32x2 t = *reinterpret_cast<const u32x2*>(p); w[0] = t.x; w[1] = t.y; }
+    }
+};
+// B operand of one k16 step for column tile nt: element j of the lane = rows[j], column nt of the lane's NT
+template <int NT>
+__device__ __forceinline__ bf16x8 bfrag(const brow<NT>* rows, int nt) {
+    const int wd = nt >> 1;
+    const uint32_t sel = (nt & 1) ? 0x07060302u : 0x05040100u;     // high or low halves of (rows[2d+1], rows[2d])
+    u32x4 f;
+    f.x = __builtin_amdgcn_perm(rows[1].w[wd], rows[0].w[wd], sel);
+    f.y = __builtin_amdgcn_perm(rows[3].w[wd], rows[2].w[wd], sel);
+    f.z = __builtin_amdgcn_perm(rows[5].w[wd], rows[4].w[wd], sel);
+    f.w = __builtin_amdgcn_perm(rows[7].w[wd], rows[6].w[wd], sel);
+    return __builtin_bit_cast(bf16x8, f);
+}
+// acc(32 x 32 NT) (+)= A . B with the A operand in the accumulator layout (lane = row, a[r] <-> k = crow(r,hh)) and
+// the 16 B rows of the lane (rows[r] = row crow(r,hh) of B, the lane's NT columns): two k16 steps of 8 registers
+template <int NT>
+__device__ __forceinline__ void mfma_ab(const float (&a)[16], const brow<NT> (&rows)[16], f32x16 (&acc)[NT]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const bf16x8 af = pack_bf16x8(a + 8 * s);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfrag<NT>(rows + 8 * s, nt), acc[nt], 0, 0, 0);
+    }
+}
+
+// tile_ay with a bf16 B-side tile [32][LDB]
+template <int HD, int LDB, bool ZERO = true>
+__device__ __forceinline__ void tile_ay(const float (&a)[16], const bf16_t* Y, int lq, int hh, f32x16 (&acc)[HD / 32]) {
+    constexpr int NT = HD / 32;
+    if constexpr (ZERO) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
+    }
+    brow<NT> rows[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rows[r].load(Y + crow(r, hh) * LDB + lq * NT);
+    mfma_ab<NT>(a, rows, acc);
 }
 
 }  // namespace

@@ -24,6 +24,7 @@
 // (and dO) element is read once, every o (dq,dk,dv) element written once; all
 // rows are 128-byte-line aligned segments of hd*s bytes.
 #include <stdlib.h>
+#include <type_traits>
 #include "attn_common.h"
 
 namespace {
@@ -106,18 +107,21 @@ __global__ __launch_bounds__(256, 2) void win_attn_fwd_k(const T* __restrict__ q
                                                          const uint32_t* __restrict__ maskbits,
                                                          const float* __restrict__ thr_p, WinGeom g,
                                                          int n_units) {
-    constexpr int LDW = HD + 4;
+    using TL = tile_of<T>;             // fp32: fp32 tiles and MFMAs; bf16: raw bf16 tiles, v_mfma_f32_32x32x16_bf16 (attn_common.h)
+    using E = typename TL::E;
+    constexpr bool B16 = sizeof(T) == 2;
+    constexpr int LDW = HD + TL::PAD;
     constexpr int NT = HD / 32;
     constexpr int EPV = io<T>::EPV;
     constexpr int CPR = HD / EPV;      // 16-byte chunks per row
     constexpr int RPI = 64 / CPR;      // rows per wave-wide load
     constexpr int NLD = 32 / RPI;      // wave-wide loads per tile
-    __shared__ __attribute__((aligned(16))) float smem[4 * 2 * 32 * LDW];
+    __shared__ __attribute__((aligned(16))) E smem[4 * 2 * 32 * LDW];
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // uniform: unit decoding in SGPRs
     const int lq = lane & 31, hh = lane >> 5;
-    float* Qs = smem + wave * (2 * 32 * LDW);
-    float* Ks = Qs + 32 * LDW;
+    E* Qs = smem + wave * (2 * 32 * LDW);
+    E* Ks = Qs + 32 * LDW;
     const int crow_l = lane / CPR, ccol = (lane % CPR) * EPV;
     const int64_t row3d = 3 * (int64_t)g.d;
     const float thr = TRAIN ? *thr_p : 0.f;
@@ -127,7 +131,9 @@ __global__ __launch_bounds__(256, 2) void win_attn_fwd_k(const T* __restrict__ q
     if (u >= n_units) return;
 
     u32x4 qr[NLD], kr[NLD];
-    float vn[16][NT];                  // V of the NEXT unit, already in the MFMA B-operand layout
+    // V of the NEXT unit, already in the MFMA B-operand layout (fp32: converted floats; bf16: the raw pairs)
+    typedef typename std::conditional<B16, brow<NT>, float[NT]>::type vrow_t;
+    vrow_t vn[16];
     // the whole next unit is requested while this one computes: Q and K as 16-byte row chunks for the LDS tiles, V
     // straight into operand registers.  (V used to be requested at the top of its own unit and was needed ~2 700
     // cycles later -- less than an HBM round trip under load, so every unit stalled on it.)
@@ -140,7 +146,10 @@ __global__ __launch_bounds__(256, 2) void win_attn_fwd_k(const T* __restrict__ q
         }
         const T* vb = qkv + 2 * g.d + un.head * HD + lq * NT;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) load_nt<T, NT>(vb + tok_of(un, crow(r, hh)) * row3d, vn[r]);
+        for (int r = 0; r < 16; ++r) {
+            if constexpr (B16) vn[r].load(vb + tok_of(un, crow(r, hh)) * row3d);
+            else load_nt<T, NT>(vb + tok_of(un, crow(r, hh)) * row3d, vn[r]);
+        }
     };
     Unit cur = decode_unit(g, u);
     issue_qkv(cur);
@@ -149,16 +158,20 @@ __global__ __launch_bounds__(256, 2) void win_attn_fwd_k(const T* __restrict__ q
         // -- stage Q (pre-scaled, HWGATE.py:89) and K into the wave's LDS tiles
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            float* dq = Qs + (i * RPI + crow_l) * LDW + ccol;
-            chunk<T>::to_lds(dq, qr[i], qk_scale<HD>());
-            chunk<T>::to_lds(dq + 32 * LDW, kr[i], 1.0f);
+            E* dq = Qs + (i * RPI + crow_l) * LDW + ccol;
+            raw_to_lds(dq, qr[i], qk_scale<HD>(), T());
+            raw_to_lds(dq + 32 * LDW, kr[i], 1.0f, T());
         }
         // -- V of this unit arrived with the previous prefetch
-        float v[16][NT];
+        vrow_t v[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
+        for (int r = 0; r < 16; ++r) {
+            if constexpr (B16) v[r] = vn[r];
+            else {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) v[r][nt] = vn[r][nt];
+                for (int nt = 0; nt < NT; ++nt) v[r][nt] = vn[r][nt];
+            }
+        }
         const uint32_t mbits = maskbits[cur.mrow + lq];
         // -- prefetch the next unit's q, k, v while this one computes
         const int un = u + nwaves;
@@ -169,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void win_attn_fwd_k(const T* __restrict__ q
         f32x16 st = tile_xyT<HD, LDW>(Ks, Qs, lq, hh);     // st[r] = S[q=lq][key=crow(r,hh)]
         float s[16], p[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = st[r];
+        for (int r = 0; r < 16; ++r) s[r] = TL::QSCALED ? st[r] : st[r] * qk_scale<HD>();
         masked_softmax<TRAIN>(s, p, mbits, hh, thr);
 
         f32x16 oacc[NT];
@@ -177,11 +190,15 @@ __global__ __launch_bounds__(256, 2) void win_attn_fwd_k(const T* __restrict__ q
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) oacc[nt][i] = 0.f;
+        if constexpr (B16) {
+            mfma_ab<NT>(p, v, oacc);
+        } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
+            for (int r = 0; r < 16; ++r)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                oacc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(p[r], v[r][nt], oacc[nt], 0, 0, 0);
+                for (int nt = 0; nt < NT; ++nt)
+                    oacc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(p[r], v[r][nt], oacc[nt], 0, 0, 0);
+        }
 
         // lane (c=lq, hh), reg r -> O[q = crow(r,hh)][c*NT + nt]
         T* ob = o + cur.head * HD + lq * NT;
@@ -199,33 +216,37 @@ __global__ __launch_bounds__(256, 2) void win_attn_fwd_k(const T* __restrict__ q
 
 // =============================================================== backward
 
+// (bf16 tiles: 18 KiB of LDS per wave instead of 34, so two 4-wave workgroups share a CU)
 template <typename T, int HD, bool TRAIN, int WAVES>
-__global__ __launch_bounds__(WAVES * 64, 1) void win_attn_bwd_k(const T* __restrict__ qkv,
+__global__ __launch_bounds__(WAVES * 64, (sizeof(T) == 2 && HD <= 64) ? 2 : 1) void win_attn_bwd_k(const T* __restrict__ qkv,
                                                                 const T* __restrict__ dO,
                                                                 T* __restrict__ dqkv,
                                                                 const uint32_t* __restrict__ maskbits,
                                                                 const float* __restrict__ thr_p,
                                                                 WinGeom g, int n_units) {
-    constexpr int LDW = HD + 4;
+    using TL = tile_of<T>;                                   // see win_attn_fwd_k
+    using E = typename TL::E;
+    constexpr int LDW = HD + TL::PAD;
     constexpr int NT = HD / 32;
     constexpr int EPV = io<T>::EPV;
     constexpr int CPR = HD / EPV;
     constexpr int RPI = 64 / CPR;
     constexpr int NLD = 32 / RPI;
     constexpr int TW = 34;                                   // transpose scratch row stride
-    constexpr int SCR = 2 * 32 * TW;                         // P^T and dS^T scratch (floats)
+    constexpr int SCR = 2 * 32 * TW;                         // P^T and dS^T scratch, in tile elements (bf16 tiles: P and dS
+                                                             // are rounded here instead of at the MFMA operand -- the same values)
     constexpr int EXTRA = (32 * LDW >= SCR) ? 0 : SCR;       // scratch aliases the V tile when it fits
     constexpr int PER_WAVE = 4 * 32 * LDW + EXTRA;
-    __shared__ __attribute__((aligned(16))) float smem[WAVES * PER_WAVE];
+    __shared__ __attribute__((aligned(16))) E smem[WAVES * PER_WAVE];
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // uniform: unit decoding in SGPRs
     const int lq = lane & 31, hh = lane >> 5;
-    float* Qs = smem + wave * PER_WAVE;
-    float* Ks = Qs + 32 * LDW;
-    float* Gs = Ks + 32 * LDW;
-    float* Vs = Gs + 32 * LDW;
-    float* Pt = EXTRA ? Vs + 32 * LDW : Vs;                   // [q][key], stride TW
-    float* Dt = Pt + 32 * TW;
+    E* Qs = smem + wave * PER_WAVE;
+    E* Ks = Qs + 32 * LDW;
+    E* Gs = Ks + 32 * LDW;
+    E* Vs = Gs + 32 * LDW;
+    E* Pt = EXTRA ? Vs + 32 * LDW : Vs;                       // [q][key], stride TW
+    E* Dt = Pt + 32 * TW;
     const int crow_l = lane / CPR, ccol = (lane % CPR) * EPV;
     const int64_t row3d = 3 * (int64_t)g.d;
     const float thr = TRAIN ? *thr_p : 0.f;
@@ -253,10 +274,10 @@ __global__ __launch_bounds__(WAVES * 64, 1) void win_attn_bwd_k(const T* __restr
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int off = (i * RPI + crow_l) * LDW + ccol;
-            chunk<T>::to_lds(Qs + off, qr[i], qk_scale<HD>());
-            chunk<T>::to_lds(Ks + off, kr[i], 1.0f);
-            chunk<T>::to_lds(Vs + off, vr[i], 1.0f);
-            chunk<T>::to_lds(Gs + off, gr[i], 1.0f);
+            raw_to_lds(Qs + off, qr[i], qk_scale<HD>(), T());
+            raw_to_lds(Ks + off, kr[i], 1.0f, T());
+            raw_to_lds(Vs + off, vr[i], 1.0f, T());
+            raw_to_lds(Gs + off, gr[i], 1.0f, T());
         }
         const uint32_t mbits = maskbits[cur.mrow + lq];
         const int un = u + nwaves;
@@ -269,7 +290,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void win_attn_bwd_k(const T* __restr
         {
             f32x16 st = tile_xyT<HD, LDW>(Ks, Qs, lq, hh);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = st[r];
+            for (int r = 0; r < 16; ++r) s[r] = TL::QSCALED ? st[r] : st[r] * qk_scale<HD>();
         }
         const uint32_t nz = masked_softmax<TRAIN>(s, p, mbits, hh, thr);
         // dP^T[key][q] = V dO^T
@@ -285,14 +306,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void win_attn_bwd_k(const T* __restr
         lds_fence();                                          // V tile is dead from here on
         // transpose P and dS through LDS: write [q][key], later read [.][key = lane]
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            float* pp = Pt + lq * TW + 8 * gq + 4 * hh;
-            float* dd = Dt + lq * TW + 8 * gq + 4 * hh;
-            f32x2 a0 = {p[4 * gq], p[4 * gq + 1]}, a1 = {p[4 * gq + 2], p[4 * gq + 3]};
-            f32x2 b0 = {ds[4 * gq], ds[4 * gq + 1]}, b1 = {ds[4 * gq + 2], ds[4 * gq + 3]};
-            reinterpret_cast<f32x2*>(pp)[0] = a0; reinterpret_cast<f32x2*>(pp)[1] = a1;
-            reinterpret_cast<f32x2*>(dd)[0] = b0; reinterpret_cast<f32x2*>(dd)[1] = b1;
-        }
+        for (int gq = 0; gq < 4; ++gq) put4(Pt + lq * TW + 8 * gq + 4 * hh, p + 4 * gq), put4(Dt + lq * TW + 8 * gq + 4 * hh, ds + 4 * gq);
         lds_fence();
 
         f32x16 acc[NT];
@@ -309,15 +323,15 @@ __global__ __launch_bounds__(WAVES * 64, 1) void win_attn_bwd_k(const T* __restr
         // dQ = scale * dS K        (A = dS in registers: lane = q)
         tile_ay<HD, LDW>(ds, Ks, lq, hh, acc);
         store_acc(gq_base, qk_scale<HD>());
-        // dK = dS^T (scale*Q)      (A = dS^T from scratch: lane = key; Qs already holds scale*Q)
+        // dK = dS^T (scale*Q)      (A = dS^T from scratch: lane = key; the fp32 Qs already holds scale*Q)
         float a[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) a[r] = Dt[crow(r, hh) * TW + lq];
+        for (int r = 0; r < 16; ++r) a[r] = (float)Dt[crow(r, hh) * TW + lq];
         tile_ay<HD, LDW>(a, Qs, lq, hh, acc);
-        store_acc(gq_base + g.d, 1.0f);
+        store_acc(gq_base + g.d, TL::QSCALED ? 1.0f : qk_scale<HD>());
         // dV = P^T dO
 #pragma unroll
-        for (int r = 0; r < 16; ++r) a[r] = Pt[crow(r, hh) * TW + lq];
+        for (int r = 0; r < 16; ++r) a[r] = (float)Pt[crow(r, hh) * TW + lq];
         tile_ay<HD, LDW>(a, Gs, lq, hh, acc);
         store_acc(gq_base + 2 * g.d, 1.0f);
         lds_fence();
@@ -335,29 +349,32 @@ __global__ __launch_bounds__(WAVES * 64, 1) void win_attn_bwd_k(const T* __restr
 // exchanged through an 8 KiB LDS mailbox (a + b on one side, b + a on the other: bit-identical, so both waves
 // run the same softmax); dQ, dK, dV split by columns and need no reduction.  160 MFMAs per wave and unit.
 template <typename T, bool TRAIN>
-__global__ __launch_bounds__(128, 2) void win_attn_bwd_split_k(const T* __restrict__ qkv, const T* __restrict__ dO,
+__global__ __launch_bounds__(128, sizeof(T) == 2 ? 3 : 2) void win_attn_bwd_split_k(const T* __restrict__ qkv, const T* __restrict__ dO,
                                                                T* __restrict__ dqkv,
                                                                const uint32_t* __restrict__ maskbits,
                                                                const float* __restrict__ thr_p, WinGeom g,
                                                                int n_units) {
-    constexpr int HD = 128, HW = 64, LDW = HW + 4, NT = HW / 32;
+    using TL = tile_of<T>;                                     // see win_attn_fwd_k
+    using E = typename TL::E;
+    constexpr int HD = 128, HW = 64, LDW = HW + TL::PAD, NT = HW / 32;
     constexpr int EPV = io<T>::EPV;
     constexpr int CPR = HW / EPV, RPI = 64 / CPR, NLD = 32 / RPI;
     constexpr int TW = 34;
     static_assert(2 * 32 * TW <= 32 * LDW, "transpose scratch must fit the dead V tile");
     constexpr int PER_WAVE = 4 * 32 * LDW;
-    __shared__ __attribute__((aligned(16))) float smem[2 * PER_WAVE + 2 * 1024];       // 77 824 B -> two workgroups per CU
+    constexpr int MBOX = 1024 * (int)(sizeof(float) / sizeof(E));         // 4 KiB mailbox per wave, in tile elements
+    __shared__ __attribute__((aligned(16))) E smem[2 * PER_WAVE + 2 * MBOX];            // fp32: 77 824 B -> two workgroups per CU
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int lq = lane & 31, hh = lane >> 5;
-    float* Qs = smem + wave * PER_WAVE;
-    float* Ks = Qs + 32 * LDW;
-    float* Gs = Ks + 32 * LDW;
-    float* Vs = Gs + 32 * LDW;
-    float* Pt = Vs;                                            // [q][key], stride TW (V is dead by then)
-    float* Dt = Pt + 32 * TW;
-    float* mine = smem + 2 * PER_WAVE + wave * 1024;           // mailbox: register quad r4 of lane l at [r4][l][4]
-    const float* theirs = smem + 2 * PER_WAVE + (wave ^ 1) * 1024;
+    E* Qs = smem + wave * PER_WAVE;
+    E* Ks = Qs + 32 * LDW;
+    E* Gs = Ks + 32 * LDW;
+    E* Vs = Gs + 32 * LDW;
+    E* Pt = Vs;                                                // [q][key], stride TW (V is dead by then)
+    E* Dt = Pt + 32 * TW;
+    float* mine = reinterpret_cast<float*>(smem + 2 * PER_WAVE + wave * MBOX);   // mailbox: register quad r4 of lane l at [r4][l][4]
+    const float* theirs = reinterpret_cast<const float*>(smem + 2 * PER_WAVE + (wave ^ 1) * MBOX);
     const int crow_l = lane / CPR, ccol = (lane % CPR) * EPV;
     const int col0 = wave * HW;
     const int64_t row3d = 3 * (int64_t)g.d;
@@ -401,10 +418,10 @@ __global__ __launch_bounds__(128, 2) void win_attn_bwd_split_k(const T* __restri
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int off = (i * RPI + crow_l) * LDW + ccol;
-            chunk<T>::to_lds(Qs + off, qr[i], qk_scale<HD>());
-            chunk<T>::to_lds(Ks + off, kr[i], 1.0f);
-            chunk<T>::to_lds(Vs + off, vr[i], 1.0f);
-            chunk<T>::to_lds(Gs + off, gr[i], 1.0f);
+            raw_to_lds(Qs + off, qr[i], qk_scale<HD>(), T());
+            raw_to_lds(Ks + off, kr[i], 1.0f, T());
+            raw_to_lds(Vs + off, vr[i], 1.0f, T());
+            raw_to_lds(Gs + off, gr[i], 1.0f, T());
         }
         const uint32_t mbits = maskbits[cur.mrow + lq];
         const int un = u + gridDim.x;
@@ -419,6 +436,10 @@ __global__ __launch_bounds__(128, 2) void win_attn_bwd_split_k(const T* __restri
             post(st);
             __syncthreads();
             collect(st, s);
+            if constexpr (!TL::QSCALED) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] *= qk_scale<HD>();
+            }
         }
         const uint32_t nz = masked_softmax<TRAIN>(s, p, mbits, hh, thr);
         // dP^T[key][q] = V dO^T, likewise
@@ -437,14 +458,7 @@ __global__ __launch_bounds__(128, 2) void win_attn_bwd_split_k(const T* __restri
         }
         lds_fence();                                          // this wave's V tile is dead from here on
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            float* pp = Pt + lq * TW + 8 * gq + 4 * hh;
-            float* dd = Dt + lq * TW + 8 * gq + 4 * hh;
-            f32x2 a0 = {p[4 * gq], p[4 * gq + 1]}, a1 = {p[4 * gq + 2], p[4 * gq + 3]};
-            f32x2 b0 = {ds[4 * gq], ds[4 * gq + 1]}, b1 = {ds[4 * gq + 2], ds[4 * gq + 3]};
-            reinterpret_cast<f32x2*>(pp)[0] = a0; reinterpret_cast<f32x2*>(pp)[1] = a1;
-            reinterpret_cast<f32x2*>(dd)[0] = b0; reinterpret_cast<f32x2*>(dd)[1] = b1;
-        }
+        for (int gq = 0; gq < 4; ++gq) put4(Pt + lq * TW + 8 * gq + 4 * hh, p + 4 * gq), put4(Dt + lq * TW + 8 * gq + 4 * hh, ds + 4 * gq);
         lds_fence();
 
         f32x16 acc[NT];
@@ -462,11 +476,11 @@ __global__ __launch_bounds__(128, 2) void win_attn_bwd_split_k(const T* __restri
         store_acc(gq_base, qk_scale<HD>());
         float a[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) a[r] = Dt[crow(r, hh) * TW + lq];
+        for (int r = 0; r < 16; ++r) a[r] = (float)Dt[crow(r, hh) * TW + lq];
         tile_ay<HW, LDW>(a, Qs, lq, hh, acc);                  // dK[:, half] = dS^T (scale Q)[:, half]
-        store_acc(gq_base + g.d, 1.0f);
+        store_acc(gq_base + g.d, TL::QSCALED ? 1.0f : qk_scale<HD>());
 #pragma unroll
-        for (int r = 0; r < 16; ++r) a[r] = Pt[crow(r, hh) * TW + lq];
+        for (int r = 0; r < 16; ++r) a[r] = (float)Pt[crow(r, hh) * TW + lq];
         tile_ay<HW, LDW>(a, Gs, lq, hh, acc);                  // dV[:, half] = P^T dO[:, half]
         store_acc(gq_base + 2 * g.d, 1.0f);
         __syncthreads();                                      // mailbox (dP) read by both before the next unit posts S
@@ -564,7 +578,7 @@ bool geom_ok(int B, int F, int nW, int nH, int hd) {
 template <typename T, int HD>
 int launch_fwd(const void* qkv, void* o, const uint32_t* mb, const float* thr, WinGeom g, int n_units,
                hipStream_t st) {
-    const int blocks = min((n_units + 3) / 4, 256 * 2);
+    const int blocks = min((n_units + 3) / 4, 256 * 2);         // (three resident workgroups with bf16 tiles: 130 vs 123 us, no gain)
     if (thr)
         win_attn_fwd_k<T, HD, true><<<blocks, 256, 0, st>>>((const T*)qkv, (T*)o, mb, thr, g, n_units);
     else
@@ -577,7 +591,7 @@ int launch_bwd(const void* qkv, const void* dO, void* dqkv, const uint32_t* mb, 
     if constexpr (HD == 128) {                               // two waves per unit, four waves per CU (see win_attn_bwd_split_k)
         static const bool whole = [] { const char* e = getenv("HWGAT_ATTN_SPLIT"); return e && e[0] == '0'; }();
         if (!whole) {
-            const int blocks = min(n_units, 256 * 2);
+            const int blocks = min(n_units, 256 * (sizeof(T) == 2 ? 3 : 2));   // bf16 tiles: 44 KiB per workgroup
             if (thr)
                 win_attn_bwd_split_k<T, true><<<blocks, 128, 0, st>>>((const T*)qkv, (const T*)dO, (T*)dqkv, mb, thr, g, n_units);
             else
@@ -586,7 +600,7 @@ int launch_bwd(const void* qkv, const void* dO, void* dqkv, const uint32_t* mb, 
         }
     }
     constexpr int WAVES = HD <= 64 ? 4 : 2;                  // 4 x 34 KiB or 2 x 66 KiB of LDS per CU
-    const int blocks = min((n_units + WAVES - 1) / WAVES, 256);
+    const int blocks = min((n_units + WAVES - 1) / WAVES, (sizeof(T) == 2 && HD <= 64) ? 512 : 256);
     if (thr)
         win_attn_bwd_k<T, HD, true, WAVES><<<blocks, WAVES * 64, 0, st>>>((const T*)qkv, (const T*)dO, (T*)dqkv, mb, thr, g, n_units);
     else
