@@ -172,6 +172,9 @@ int hwgat_merge(const void* in, void* out, int B, int F, int K, int d, int inver
  *        2  C2 = acc + bias ; C = dropout(gelu(C2))   (exact-erf GELU)
  *        3  C = acc * dropmask * gelu'(aux)           (backward of epi 2; aux = saved C2)
  *        4  C = acc
+ *        5  C2 = gelu'(acc + bias) * dropmask ; C = dropout(gelu(acc + bias))   (training form of epi 2: the factor the
+ *           backward needs is stored instead of the pre-activation)
+ *        6  C = acc * aux                             (backward of epi 5; aux = its saved C2)
  *   bias may be NULL (treated as 0).  For dX pass W = transposed weight. */
 int hwgat_linear_nt_f32(const float* A, const float* W, const float* bias, float* C, int64_t M, int N,
                         int K, int pro, const float* mean, const float* rstd, const float* gamma,

@@ -9,7 +9,8 @@ forward  (4 GEMM launches + 1 attention; the reference runs ~40 ATen ops):
     o                = window attention(qkv)                           (hwgat_win_attn_fwd)
     y                = x + drop(o Wp^T + b)     bias+dropout+residual in the GEMM epilogue, which also accumulates the
                        row sums / sums of squares of y -> stats2 (hwgat_linear_nt_f32_ex + hwgat_ln_finalize)
-    h1, u            = LN2(y) W1^T + b ; u = drop(gelu(h1))            GEMM prologue + epilogue
+    h1, u            = LN2(y) W1^T + b ; u = drop(gelu(h1))            GEMM epilogue; what is SAVED as h1 is gelu'(h1) * mask,
+                       so the backward dX launch only multiplies by it
     out              = y + drop(u W2^T + b)     same epilogue: statistics of `out` for the next block's LN1, and at a
                        stage end the store goes straight to the TemporalMerging layout (HWGATE.py:55-63)
 saved for backward: x, qkv, o, y, h1, u and the row statistics (10 E floats); LN outputs and
@@ -84,7 +85,8 @@ class _FusedBlock(torch.autograd.Function):
         else:
             y = HF.linear_nt(o, cw(wp), bp, epi=HF.EPI_BIAS_DROP_RES, res=x, epi_seed=seeds[0], epi_p=p)
             m2, r2 = HF.ln_stats(y, n2w, n2b)
-        u, h1 = HF.linear_nt_ln(y, w1, b1, (m2, r2, n2w, n2b), epi=HF.EPI_BIAS_GELU_DROP, epi_seed=seeds[1], epi_p=p)
+        # h1 here is gelu'(pre-activation) * dropout mask, the factor the backward multiplies by (EPI_BIAS_GELU_DROP_G)
+        u, h1 = HF.linear_nt_ln(y, w1, b1, (m2, r2, n2w, n2b), epi=HF.EPI_BIAS_GELU_DROP_G, epi_seed=seeds[1], epi_p=p)
         merged = bool(merge_out and fuse)
         if fuse and (want_stats or merged):
             out, mo, ro = HF.linear_nt(u, cw(w2), b2, epi=HF.EPI_BIAS_DROP_RES, res=y, epi_seed=seeds[2], epi_p=p,
@@ -124,7 +126,7 @@ class _FusedBlock(torch.autograd.Function):
         # ---- FFN branch: out = y + drop3(u W2^T + b2), u = drop2(gelu(h1)), h1 = LN2(y) W1^T + b1
         dwq.run(lambda: HF.linear_tn(dout, u, dw2, db2, pro_seed=seeds[2], pro_p=p))
         d_h1 = HF.linear_nt(dout, HF.transpose(w2, dt), None, pro=HF.PRO_DROP, pro_seed=seeds[2], pro_p=p,
-                            epi=HF.EPI_GELU_BWD, aux=h1, epi_seed=seeds[1], epi_p=p)
+                            epi=HF.EPI_MUL_AUX, aux=h1)
         dwq.run(lambda: HF.linear_tn(d_h1, y, dw1, db1, ln=(m2, r2, n2w, n2b)))
         d_z = HF.linear_nt(d_h1, HF.transpose(w1, dt), None, epi=HF.EPI_NONE)
         d_y = HF.ln_backward(d_z, y, m2, r2, n2w, dout, dn2w, dn2b)          # + shortcut gradient

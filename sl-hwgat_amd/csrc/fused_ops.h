@@ -9,7 +9,15 @@
 enum { PRO_NONE = 0, PRO_LN = 1, PRO_DROP = 2, PRO_LN_FOLD = 3 };
 // extra work of an NT epilogue (template parameter STAT of the NT kernels)
 enum { X_NONE = 0, X_STAT = 1, X_STAT_MERGE = 2, X_LNFOLD = 3 };
-enum { EPI_BIAS = 0, EPI_BIAS_DROP_RES = 1, EPI_BIAS_GELU_DROP = 2, EPI_GELU_BWD = 3, EPI_NONE = 4 };
+// EPI_BIAS_GELU_DROP_G / EPI_MUL_AUX: the training pair of the MLP's first linear.  The forward epilogue has
+// Phi(x) and phi(x) in hand anyway, so it stores  gelu'(x) * mask  (C2) instead of the pre-activation, and the backward
+// dX launch only multiplies by it -- no erf / exp / mask hash in the backward epilogue, where nothing hides them
+// (EPI_GELU_BWD cost its launch +130 us at stage 2, fp32 and bf16 alike).
+enum { EPI_BIAS = 0, EPI_BIAS_DROP_RES = 1, EPI_BIAS_GELU_DROP = 2, EPI_GELU_BWD = 3, EPI_NONE = 4,
+       EPI_BIAS_GELU_DROP_G = 5, EPI_MUL_AUX = 6 };
+constexpr bool epi_has_bias(int e) { return e == EPI_BIAS || e == EPI_BIAS_DROP_RES || e == EPI_BIAS_GELU_DROP || e == EPI_BIAS_GELU_DROP_G; }
+constexpr bool epi_reads_extra(int e) { return e == EPI_BIAS_DROP_RES || e == EPI_GELU_BWD || e == EPI_MUL_AUX; }   // res, else aux
+constexpr bool epi_drops(int e) { return e == EPI_BIAS_DROP_RES || e == EPI_BIAS_GELU_DROP || e == EPI_BIAS_GELU_DROP_G || e == EPI_GELU_BWD; }
 
 // Dropout mask: a counter-based hash of (seed, element index).  One 32-bit hash serves an
 // aligned PAIR of elements (16 bits each): keep iff its 16 bits >= p * 65536 (p is thereby
@@ -63,6 +71,13 @@ __device__ __forceinline__ float gelu_f(float x) {
     float cdf, pdf;
     gelu_parts(x, cdf, pdf);
     return x * cdf;
+}
+// u = gelu(x) * keep, g = gelu'(x) * keep from one evaluation of (Phi, phi)
+__device__ __forceinline__ void gelu_fwd_grad(float x, float keep, float& u, float& g) {
+    float cdf, pdf;
+    gelu_parts(x, cdf, pdf);
+    u = x * cdf * keep;
+    g = fmaf(x, pdf, cdf) * keep;
 }
 __device__ __forceinline__ float gelu_grad(float x) {
     float cdf, pdf;

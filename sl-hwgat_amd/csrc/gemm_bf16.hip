@@ -178,7 +178,7 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt
         for (int jc = 0; jc < TNW * 32 / SW; ++jc) {
             const int col = n0 + wn * (TNW * 32) + jc * SW + ec;
             f32x4 bv0 = {0.f, 0.f, 0.f, 0.f}, bv1 = bv0;
-            if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_DROP_RES || EPI == EPI_BIAS_GELU_DROP)
+            if constexpr (epi_has_bias(EPI))
                 if (p.bias) { bv0 = *reinterpret_cast<const f32x4*>(p.bias + col); bv1 = *reinterpret_cast<const f32x4*>(p.bias + col + 4); }
             f32x4 sv0 = bv0, sv1 = bv0, cv0 = bv0, cv1 = bv0;  // X_LNFOLD: s_n and c_n of the lane's 8 columns
             if constexpr (STAT == X_LNFOLD) {
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt
                 MergeWalk mw;
                 if constexpr (STAT == X_STAT_MERGE) mw.start(m0 + wm * (TMW * 32) + i * 32 + er, p.mg_F, p.mg_K, RPS);
                 u32x4 ex[NPS];
-                if constexpr (EPI == EPI_BIAS_DROP_RES || EPI == EPI_GELU_BWD) {
+                if constexpr (epi_reads_extra(EPI)) {
                     const bf16_t* src = EPI == EPI_BIAS_DROP_RES ? p.res : p.aux;
 #pragma unroll
                     for (int ps = 0; ps < NPS; ++ps) {
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt
                     }
                     float o8[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
                     float dk[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
-                    if constexpr (EPI == EPI_BIAS_DROP_RES || EPI == EPI_BIAS_GELU_DROP || EPI == EPI_GELU_BWD) {
+                    if constexpr (epi_drops(EPI)) {
                         if (epi_th) {
                             const uint64_t e0 = (uint64_t)(off + (RAGGED ? p.row0 * p.N : 0));
                             const f32x4 k0 = drop_keep4(p.epi_seed, e0, epi_th, epi_sc), k1 = drop_keep4(p.epi_seed, e0 + 4, epi_th, epi_sc);
@@ -250,6 +250,16 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt
                         unpack8(pre, h);                       // gelu on the bf16-rounded pre-activation that backward will see
 #pragma unroll
                         for (int e = 0; e < 8; ++e) o8[e] = gelu_f(h[e]) * dk[e];
+                    } else if constexpr (EPI == EPI_BIAS_GELU_DROP_G) {
+                        float g8[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) gelu_fwd_grad(o8[e], dk[e], o8[e], g8[e]);
+                        *reinterpret_cast<u32x4*>(p.C2 + off) = pack8(g8);
+                    } else if constexpr (EPI == EPI_MUL_AUX) {
+                        float h[8];
+                        unpack8(ex[ps], h);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o8[e] *= h[e];
                     } else if constexpr (EPI == EPI_GELU_BWD) {
                         float h[8];
                         unpack8(ex[ps], h);
@@ -487,6 +497,7 @@ int launch_nt_b(const NtArgsB& a, int epi, hipStream_t st, bool fold = false) {
         if constexpr (PRO == PRO_NONE) {
             if (epi == EPI_BIAS) gemm_nt_bf16_k<PRO_NONE, EPI_BIAS, C, RAGGED, X_LNFOLD><<<grid, C::THREADS, 0, st>>>(a);
             else if (epi == EPI_BIAS_GELU_DROP) gemm_nt_bf16_k<PRO_NONE, EPI_BIAS_GELU_DROP, C, RAGGED, X_LNFOLD><<<grid, C::THREADS, 0, st>>>(a);
+            else if (epi == EPI_BIAS_GELU_DROP_G) gemm_nt_bf16_k<PRO_NONE, EPI_BIAS_GELU_DROP_G, C, RAGGED, X_LNFOLD><<<grid, C::THREADS, 0, st>>>(a);
             else return HWGAT_EINVAL;
             HWGAT_LAUNCH_CHECK();
         }
@@ -505,6 +516,8 @@ int launch_nt_b(const NtArgsB& a, int epi, hipStream_t st, bool fold = false) {
         case EPI_BIAS_DROP_RES: gemm_nt_bf16_k<PRO, EPI_BIAS_DROP_RES, C, RAGGED><<<grid, C::THREADS, 0, st>>>(a); break;
         case EPI_BIAS_GELU_DROP: gemm_nt_bf16_k<PRO, EPI_BIAS_GELU_DROP, C, RAGGED><<<grid, C::THREADS, 0, st>>>(a); break;
         case EPI_GELU_BWD: gemm_nt_bf16_k<PRO, EPI_GELU_BWD, C, RAGGED><<<grid, C::THREADS, 0, st>>>(a); break;
+        case EPI_BIAS_GELU_DROP_G: gemm_nt_bf16_k<PRO, EPI_BIAS_GELU_DROP_G, C, RAGGED><<<grid, C::THREADS, 0, st>>>(a); break;
+        case EPI_MUL_AUX: gemm_nt_bf16_k<PRO, EPI_MUL_AUX, C, RAGGED><<<grid, C::THREADS, 0, st>>>(a); break;
         case EPI_NONE: gemm_nt_bf16_k<PRO, EPI_NONE, C, RAGGED><<<grid, C::THREADS, 0, st>>>(a); break;
         default: return HWGAT_EINVAL;
     }
@@ -535,12 +548,12 @@ extern "C" int hwgat_linear_nt_bf16_ex(const void* A, const void* W, const float
     if (N % 128 || K % 64 || ((M + 127) / 128) * (int64_t)(N / 128) > 0x7fffffff) return HWGAT_ESHAPE;   // any M
     if ((pro == PRO_LN || pro == PRO_LN_FOLD) && (!mean || !rstd || !gamma || !beta)) return HWGAT_EINVAL;
     if (pro == PRO_LN_FOLD) {                                      // gamma = s[N], beta = c[N] of hwgat_ln_fold; whole tiles
-        if (epi != EPI_BIAS && epi != EPI_BIAS_GELU_DROP) return HWGAT_EINVAL;
+        if (epi != EPI_BIAS && epi != EPI_BIAS_GELU_DROP && epi != EPI_BIAS_GELU_DROP_G) return HWGAT_EINVAL;
         if (M % 128) return HWGAT_ESHAPE;
     }
     if (epi == EPI_BIAS_DROP_RES && !res) return HWGAT_EINVAL;
-    if (epi == EPI_BIAS_GELU_DROP && !C2) return HWGAT_EINVAL;
-    if (epi == EPI_GELU_BWD && !aux) return HWGAT_EINVAL;
+    if ((epi == EPI_BIAS_GELU_DROP || epi == EPI_BIAS_GELU_DROP_G) && !C2) return HWGAT_EINVAL;
+    if ((epi == EPI_GELU_BWD || epi == EPI_MUL_AUX) && !aux) return HWGAT_EINVAL;
     if (pro_p < 0.f || pro_p >= 1.f || epi_p < 0.f || epi_p >= 1.f) return HWGAT_EINVAL;
     if (pro == PRO_DROP && pro_p == 0.f) pro = PRO_NONE;          // eval mode: no mask to hash
     const bool stat = stat_sum != nullptr || stat_sq != nullptr || merge_K > 0;

@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_bf16_k(NtArgsB p) {
             static_assert(STAT == X_NONE || STAT == X_LNFOLD || (4 * 32 * SLD + 4 * BT) * 4 <= BUFB, "no room for the row statistics");
             const int col = n0 + wn * 128 + ec;
             f32x4 bv0 = {0.f, 0.f, 0.f, 0.f}, bv1 = bv0;
-            if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_DROP_RES || EPI == EPI_BIAS_GELU_DROP)
+            if constexpr (epi_has_bias(EPI))
                 if (p.bias) { bv0 = *reinterpret_cast<const f32x4*>(p.bias + col); bv1 = *reinterpret_cast<const f32x4*>(p.bias + col + 4); }
             f32x4 sv0 = bv0, sv1 = bv0, cv0 = bv0, cv1 = bv0;  // X_LNFOLD: s_n and c_n of the lane's 8 columns
             if constexpr (STAT == X_LNFOLD) {
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_bf16_k(NtArgsB p) {
                 MergeWalk mw;
                 if constexpr (STAT == X_STAT_MERGE) mw.start(m0 + wm * 128 + i * 32 + er, p.mg_F, p.mg_K, 4);
                 u32x4 ex[8];                                    // residual / pre-activation of the piece: in flight while it is parked
-                if constexpr (EPI == EPI_BIAS_DROP_RES || EPI == EPI_GELU_BWD) {
+                if constexpr (epi_reads_extra(EPI)) {
                     const bf16_t* src = (EPI == EPI_BIAS_DROP_RES ? p.res : p.aux) + off0;
 #pragma unroll
                     for (int ps = 0; ps < 8; ++ps) ex[ps] = *reinterpret_cast<const u32x4*>(src + ps * rs4);
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_bf16_k(NtArgsB p) {
                     }
                     float o8[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
                     float dk[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
-                    if constexpr (EPI == EPI_BIAS_DROP_RES || EPI == EPI_BIAS_GELU_DROP || EPI == EPI_GELU_BWD) {
+                    if constexpr (epi_drops(EPI)) {
                         if (epi_th) {
                             const f32x4 k0 = drop_keep4(p.epi_seed, (uint64_t)off, epi_th, epi_sc), k1 = drop_keep4(p.epi_seed, (uint64_t)off + 4, epi_th, epi_sc);
                             dk[0] = k0.x; dk[1] = k0.y; dk[2] = k0.z; dk[3] = k0.w; dk[4] = k1.x; dk[5] = k1.y; dk[6] = k1.z; dk[7] = k1.w;
@@ -273,6 +273,16 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_bf16_k(NtArgsB p) {
                         unpack8(pre, h);                       // gelu on the bf16-rounded pre-activation that backward will see
 #pragma unroll
                         for (int e = 0; e < 8; ++e) o8[e] = gelu_f(h[e]) * dk[e];
+                    } else if constexpr (EPI == EPI_BIAS_GELU_DROP_G) {
+                        float g8[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) gelu_fwd_grad(o8[e], dk[e], o8[e], g8[e]);
+                        *reinterpret_cast<u32x4*>(p.C2 + off) = pack8(g8);
+                    } else if constexpr (EPI == EPI_MUL_AUX) {
+                        float h[8];
+                        unpack8(ex[ps], h);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o8[e] *= h[e];
                     } else if constexpr (EPI == EPI_GELU_BWD) {
                         float h[8];
                         unpack8(ex[ps], h);
@@ -331,6 +341,7 @@ int launch(const NtArgsB& a, int epi, int grid, hipStream_t st, bool fold = fals
         if constexpr (PRO == PRO_NONE) {
             if (epi == EPI_BIAS) gemm_nt256_bf16_k<PRO_NONE, EPI_BIAS, X_LNFOLD><<<grid, 256, 0, st>>>(a);
             else if (epi == EPI_BIAS_GELU_DROP) gemm_nt256_bf16_k<PRO_NONE, EPI_BIAS_GELU_DROP, X_LNFOLD><<<grid, 256, 0, st>>>(a);
+            else if (epi == EPI_BIAS_GELU_DROP_G) gemm_nt256_bf16_k<PRO_NONE, EPI_BIAS_GELU_DROP_G, X_LNFOLD><<<grid, 256, 0, st>>>(a);
             else return HWGAT_EINVAL;
             HWGAT_LAUNCH_CHECK();
         }
@@ -341,6 +352,8 @@ int launch(const NtArgsB& a, int epi, int grid, hipStream_t st, bool fold = fals
         case EPI_BIAS_DROP_RES: gemm_nt256_bf16_k<PRO, EPI_BIAS_DROP_RES><<<grid, 256, 0, st>>>(a); break;
         case EPI_BIAS_GELU_DROP: gemm_nt256_bf16_k<PRO, EPI_BIAS_GELU_DROP><<<grid, 256, 0, st>>>(a); break;
         case EPI_GELU_BWD: gemm_nt256_bf16_k<PRO, EPI_GELU_BWD><<<grid, 256, 0, st>>>(a); break;
+        case EPI_BIAS_GELU_DROP_G: gemm_nt256_bf16_k<PRO, EPI_BIAS_GELU_DROP_G><<<grid, 256, 0, st>>>(a); break;
+        case EPI_MUL_AUX: gemm_nt256_bf16_k<PRO, EPI_MUL_AUX><<<grid, 256, 0, st>>>(a); break;
         case EPI_NONE: gemm_nt256_bf16_k<PRO, EPI_NONE><<<grid, 256, 0, st>>>(a); break;
         default: return HWGAT_EINVAL;
     }

@@ -203,7 +203,7 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt
             for (int jc = 0; jc < TNW * 32 / SW; ++jc) {
                 const int col = n0 + wn * (TNW * 32) + jc * SW + ec;
                 f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-                if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_DROP_RES || EPI == EPI_BIAS_GELU_DROP)
+                if constexpr (epi_has_bias(EPI))
                     if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + col);
                 f32x4 sv = bv, cv = bv;                         // X_LNFOLD: s_n and c_n of the lane's columns
                 if constexpr (STAT == X_LNFOLD) {
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt
                     MergeWalk mw;
                     if constexpr (STAT == X_STAT_MERGE) mw.start(m0 + wm * (TMW * 32) + i * 32 + er, p.mg_F, p.mg_K, RPS);
                     f32x4 ex[NPS];
-                    if constexpr (EPI == EPI_BIAS_DROP_RES || EPI == EPI_GELU_BWD) {
+                    if constexpr (epi_reads_extra(EPI)) {
                         const float* src = EPI == EPI_BIAS_DROP_RES ? p.res : p.aux;
 #pragma unroll
                         for (int ps = 0; ps < NPS; ++ps) {
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt
                         if constexpr (STAT == X_LNFOLD) v = v * rr_[ps] + (cv - sv * (rm[ps] * rr_[ps]));
                         else v += bv;
                         f32x4 dk = {1.f, 1.f, 1.f, 1.f};
-                        if constexpr (EPI == EPI_BIAS_DROP_RES || EPI == EPI_BIAS_GELU_DROP || EPI == EPI_GELU_BWD) {
+                        if constexpr (epi_drops(EPI)) {
                             if (epi_th) dk = drop_keep4(p.epi_seed, (uint64_t)(off + (RAGGED ? p.row0 * p.N : 0)), epi_th, epi_sc);
                         }
                         if constexpr (EPI == EPI_BIAS_DROP_RES) {
@@ -263,6 +263,16 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt
                             *reinterpret_cast<f32x4*>(p.C2 + off) = v;
                             v.x = gelu_f(v.x) * dk.x; v.y = gelu_f(v.y) * dk.y;
                             v.z = gelu_f(v.z) * dk.z; v.w = gelu_f(v.w) * dk.w;
+                        } else if constexpr (EPI == EPI_BIAS_GELU_DROP_G) {
+                            float u4[4] = {v.x, v.y, v.z, v.w}, g4[4];
+                            const float k4[4] = {dk.x, dk.y, dk.z, dk.w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) gelu_fwd_grad(u4[e], k4[e], u4[e], g4[e]);
+                            v = f32x4{u4[0], u4[1], u4[2], u4[3]};
+                            const f32x4 gq = {g4[0], g4[1], g4[2], g4[3]};
+                            *reinterpret_cast<f32x4*>(p.C2 + off) = gq;
+                        } else if constexpr (EPI == EPI_MUL_AUX) {
+                            v *= ex[ps];
                         } else if constexpr (EPI == EPI_GELU_BWD) {
                             const f32x4 h = ex[ps];
                             v.x *= dk.x * gelu_grad(h.x); v.y *= dk.y * gelu_grad(h.y);
@@ -494,6 +504,7 @@ int launch_nt(const NtArgs& a, int epi, hipStream_t st, bool fold = false) {
         if constexpr (PRO == PRO_NONE) {
             if (epi == EPI_BIAS) gemm_nt_k<PRO_NONE, EPI_BIAS, C, RAGGED, X_LNFOLD><<<grid, C::THREADS, 0, st>>>(a);
             else if (epi == EPI_BIAS_GELU_DROP) gemm_nt_k<PRO_NONE, EPI_BIAS_GELU_DROP, C, RAGGED, X_LNFOLD><<<grid, C::THREADS, 0, st>>>(a);
+            else if (epi == EPI_BIAS_GELU_DROP_G) gemm_nt_k<PRO_NONE, EPI_BIAS_GELU_DROP_G, C, RAGGED, X_LNFOLD><<<grid, C::THREADS, 0, st>>>(a);
             else return HWGAT_EINVAL;
             HWGAT_LAUNCH_CHECK();
         }
@@ -512,6 +523,8 @@ int launch_nt(const NtArgs& a, int epi, hipStream_t st, bool fold = false) {
         case EPI_BIAS_DROP_RES: gemm_nt_k<PRO, EPI_BIAS_DROP_RES, C, RAGGED><<<grid, C::THREADS, 0, st>>>(a); break;
         case EPI_BIAS_GELU_DROP: gemm_nt_k<PRO, EPI_BIAS_GELU_DROP, C, RAGGED><<<grid, C::THREADS, 0, st>>>(a); break;
         case EPI_GELU_BWD: gemm_nt_k<PRO, EPI_GELU_BWD, C, RAGGED><<<grid, C::THREADS, 0, st>>>(a); break;
+        case EPI_BIAS_GELU_DROP_G: gemm_nt_k<PRO, EPI_BIAS_GELU_DROP_G, C, RAGGED><<<grid, C::THREADS, 0, st>>>(a); break;
+        case EPI_MUL_AUX: gemm_nt_k<PRO, EPI_MUL_AUX, C, RAGGED><<<grid, C::THREADS, 0, st>>>(a); break;
         case EPI_NONE: gemm_nt_k<PRO, EPI_NONE, C, RAGGED><<<grid, C::THREADS, 0, st>>>(a); break;
         default: return HWGAT_EINVAL;
     }
@@ -587,12 +600,12 @@ extern "C" int hwgat_linear_nt_f32_ex(const float* A, const float* W, const floa
     if (N % 128 || K % 32 || ((M + 127) / 128) * (int64_t)(N / 128) > 0x7fffffff) return HWGAT_ESHAPE;   // any M
     if ((pro == PRO_LN || pro == PRO_LN_FOLD) && (!mean || !rstd || !gamma || !beta)) return HWGAT_EINVAL;
     if (pro == PRO_LN_FOLD) {                                      // gamma = s[N], beta = c[N] of hwgat_ln_fold; whole tiles
-        if (epi != EPI_BIAS && epi != EPI_BIAS_GELU_DROP) return HWGAT_EINVAL;
+        if (epi != EPI_BIAS && epi != EPI_BIAS_GELU_DROP && epi != EPI_BIAS_GELU_DROP_G) return HWGAT_EINVAL;
         if (M % 128) return HWGAT_ESHAPE;
     }
     if (epi == EPI_BIAS_DROP_RES && !res) return HWGAT_EINVAL;
-    if (epi == EPI_BIAS_GELU_DROP && !C2) return HWGAT_EINVAL;
-    if (epi == EPI_GELU_BWD && !aux) return HWGAT_EINVAL;
+    if ((epi == EPI_BIAS_GELU_DROP || epi == EPI_BIAS_GELU_DROP_G) && !C2) return HWGAT_EINVAL;
+    if ((epi == EPI_GELU_BWD || epi == EPI_MUL_AUX) && !aux) return HWGAT_EINVAL;
     if (pro_p < 0.f || pro_p >= 1.f || epi_p < 0.f || epi_p >= 1.f) return HWGAT_EINVAL;
     const bool stat = stat_sum != nullptr || stat_sq != nullptr || merge_K > 0;
     if (stat) {
@@ -651,7 +664,7 @@ extern "C" int hwgat_linear_nt_f32_ex(const float* A, const float* W, const floa
             default: return HWGAT_EINVAL;
         }
     }
-    const bool heavy = epi == EPI_BIAS_DROP_RES || epi == EPI_BIAS_GELU_DROP || epi == EPI_GELU_BWD;
+    const bool heavy = epi == EPI_BIAS_DROP_RES || epi == EPI_BIAS_GELU_DROP || epi == EPI_GELU_BWD || epi == EPI_BIAS_GELU_DROP_G || epi == EPI_MUL_AUX;
     const bool big = tile_override() == 2 && (M % 256 == 0) && (N % 256 == 0);
     const bool k16 = tile_override() == 3 || (tile_override() == 0 && heavy);
 #define NT_GO(P) return big ? launch_nt<P, NtBig>(a, epi, st) : (k16 ? launch_nt<P, NtK16>(a, epi, st) : launch_nt<P, NtSmall>(a, epi, st))

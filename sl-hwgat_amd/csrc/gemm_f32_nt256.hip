@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_k(NtArgs p) {
             static_assert(STAT == X_NONE || STAT == X_LNFOLD || 4 * 32 * SLD + 4 * BT <= BUF, "no room for the row statistics");
             const int col = n0 + wn * 128 + ec;
             f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-            if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_DROP_RES || EPI == EPI_BIAS_GELU_DROP)
+            if constexpr (epi_has_bias(EPI))
                 if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + col);
             f32x4 sv = bv, cv = bv;                             // X_LNFOLD: s_n and c_n of the lane's columns
             if constexpr (STAT == X_LNFOLD) {
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_k(NtArgs p) {
                 if constexpr (STAT == X_STAT_MERGE) mw.start(m0 + wm * 128 + i * 32 + er, p.mg_F, p.mg_K, 2);
                 // operands of this piece (residual / pre-activation): in flight while the piece is parked
                 f32x4 ex[16];
-                if constexpr (EPI == EPI_BIAS_DROP_RES || EPI == EPI_GELU_BWD) {
+                if constexpr (epi_reads_extra(EPI)) {
                     const float* src = (EPI == EPI_BIAS_DROP_RES ? p.res : p.aux) + off0;
 #pragma unroll
                     for (int ps = 0; ps < 16; ++ps) ex[ps] = *reinterpret_cast<const f32x4*>(src + ps * rs2);
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_k(NtArgs p) {
                     if constexpr (STAT == X_LNFOLD) v = v * rr[ps] + (cv - sv * (rm[ps] * rr[ps]));
                     else v += bv;
                     f32x4 dk = {1.f, 1.f, 1.f, 1.f};
-                    if constexpr (EPI == EPI_BIAS_DROP_RES || EPI == EPI_BIAS_GELU_DROP || EPI == EPI_GELU_BWD) {
+                    if constexpr (epi_drops(EPI)) {
                         dk = drop_keep4(p.epi_seed, (uint64_t)off, epi_th, epi_sc);
                     }
                     if constexpr (EPI == EPI_BIAS_DROP_RES) {
@@ -269,6 +269,16 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_k(NtArgs p) {
                         *reinterpret_cast<f32x4*>(p.C2 + off) = v;
                         v.x = gelu_f(v.x) * dk.x; v.y = gelu_f(v.y) * dk.y;
                         v.z = gelu_f(v.z) * dk.z; v.w = gelu_f(v.w) * dk.w;
+                    } else if constexpr (EPI == EPI_BIAS_GELU_DROP_G) {
+                        float u4[4] = {v.x, v.y, v.z, v.w}, g4[4];
+                        const float k4[4] = {dk.x, dk.y, dk.z, dk.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) gelu_fwd_grad(u4[e], k4[e], u4[e], g4[e]);
+                        v = f32x4{u4[0], u4[1], u4[2], u4[3]};
+                        const f32x4 gq = {g4[0], g4[1], g4[2], g4[3]};
+                        *reinterpret_cast<f32x4*>(p.C2 + off) = gq;
+                    } else if constexpr (EPI == EPI_MUL_AUX) {
+                        v *= ex[ps];
                     } else if constexpr (EPI == EPI_GELU_BWD) {
                         const f32x4 h = ex[ps];
                         v.x *= dk.x * gelu_grad(h.x); v.y *= dk.y * gelu_grad(h.y);
@@ -321,6 +331,7 @@ int launch(const NtArgs& a, int epi, int grid, hipStream_t st, bool fold = false
         if constexpr (PRO == PRO_NONE) {
             if (epi == EPI_BIAS) gemm_nt256_k<PRO_NONE, EPI_BIAS, X_LNFOLD><<<grid, 256, 0, st>>>(a);
             else if (epi == EPI_BIAS_GELU_DROP) gemm_nt256_k<PRO_NONE, EPI_BIAS_GELU_DROP, X_LNFOLD><<<grid, 256, 0, st>>>(a);
+            else if (epi == EPI_BIAS_GELU_DROP_G) gemm_nt256_k<PRO_NONE, EPI_BIAS_GELU_DROP_G, X_LNFOLD><<<grid, 256, 0, st>>>(a);
             else return HWGAT_EINVAL;
             HWGAT_LAUNCH_CHECK();
         }
@@ -331,6 +342,8 @@ int launch(const NtArgs& a, int epi, int grid, hipStream_t st, bool fold = false
         case EPI_BIAS_DROP_RES: gemm_nt256_k<PRO, EPI_BIAS_DROP_RES><<<grid, 256, 0, st>>>(a); break;
         case EPI_BIAS_GELU_DROP: gemm_nt256_k<PRO, EPI_BIAS_GELU_DROP><<<grid, 256, 0, st>>>(a); break;
         case EPI_GELU_BWD: gemm_nt256_k<PRO, EPI_GELU_BWD><<<grid, 256, 0, st>>>(a); break;
+        case EPI_BIAS_GELU_DROP_G: gemm_nt256_k<PRO, EPI_BIAS_GELU_DROP_G><<<grid, 256, 0, st>>>(a); break;
+        case EPI_MUL_AUX: gemm_nt256_k<PRO, EPI_MUL_AUX><<<grid, 256, 0, st>>>(a); break;
         case EPI_NONE: gemm_nt256_k<PRO, EPI_NONE><<<grid, 256, 0, st>>>(a); break;
         default: return HWGAT_EINVAL;
     }

@@ -331,7 +331,7 @@ PRO_NONE, PRO_LN, PRO_DROP, PRO_LN_FOLD = 0, 1, 2, 3
 # the GEMM epilogue (hwgat_ln_fold + pro 3) when the token count is whole tiles; HWGAT_LN_FOLD=0 keeps the
 # in-kernel normalising loader (pro 1) everywhere.
 LN_FOLD = os.environ.get("HWGAT_LN_FOLD", "1") != "0"
-EPI_BIAS, EPI_BIAS_DROP_RES, EPI_BIAS_GELU_DROP, EPI_GELU_BWD, EPI_NONE = 0, 1, 2, 3, 4
+EPI_BIAS, EPI_BIAS_DROP_RES, EPI_BIAS_GELU_DROP, EPI_GELU_BWD, EPI_NONE, EPI_BIAS_GELU_DROP_G, EPI_MUL_AUX = 0, 1, 2, 3, 4, 5, 6
 
 
 def can_fuse_row_stats(x):
@@ -342,7 +342,7 @@ def can_fuse_row_stats(x):
 def linear_nt(A, W, bias=None, *, pro=PRO_NONE, ln=None, pro_seed=0, pro_p=0.0, epi=EPI_BIAS,
               res=None, aux=None, epi_seed=0, epi_p=0.0, out=None, stats=False, merge=None):
     """C[M,N] = pro(A)[M,K] . W[N,K]^T with fused epilogue (see include/hwgat_hip.h).
-    Returns C, or (C, C2) for EPI_BIAS_GELU_DROP (C2 = pre-activation).
+    Returns C, or (C, C2) for EPI_BIAS_GELU_DROP (C2 = pre-activation) / EPI_BIAS_GELU_DROP_G (C2 = gelu' * mask).
     EPI_BIAS_DROP_RES: `stats=True` also returns (mean, rstd) of the OUTPUT rows, produced by the epilogue
     (no separate pass over C); `merge=(F, K_tok)` stores C in the TemporalMerging layout (B, F/2, K_tok, 2N)
     (HWGATE.py:55-63), statistics then per merged row.  Returns (C, mean, rstd)."""
@@ -369,7 +369,7 @@ def linear_nt(A, W, bias=None, *, pro=PRO_NONE, ln=None, pro_seed=0, pro_p=0.0, 
         call("hwgat_ln_finalize", ptr(st[0]), ptr(st[1]), rows, width, stream())
         return C, st[0], st[1]
     C = out if out is not None else torch.empty(*A.shape[:-1], N, device=A.device, dtype=A.dtype)
-    C2 = torch.empty_like(C) if epi == EPI_BIAS_GELU_DROP else None
+    C2 = torch.empty_like(C) if epi in (EPI_BIAS_GELU_DROP, EPI_BIAS_GELU_DROP_G) else None
     mean = rstd = gamma = beta = None
     if pro in (PRO_LN, PRO_LN_FOLD):
         mean, rstd, gamma, beta = ln

@@ -454,3 +454,31 @@ def test_layernorm_folded_into_weights_and_epilogue(M, N, K, dtype):
     # and it is the same function as the normalising loader (pro 1) up to rounding
     old = HF.linear_nt(Ad, W.to(DEV).to(dt), b.to(DEV), pro=HF.PRO_LN, ln=ln)
     assert rel_err(got.float().cpu(), old.float().cpu().double()) < (3e-5 if dtype == "f32" else 1.5e-2)
+
+
+# ---- the training pair of the MLP's first linear: EPI_BIAS_GELU_DROP_G stores gelu'(pre) * mask beside the
+# activation, EPI_MUL_AUX multiplies the backward product by it (together = EPI_BIAS_GELU_DROP + EPI_GELU_BWD)
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("M,N,K", [(128 * 5, 384, 128), (256 * 3 + 128, 512, 256)])
+def test_gelu_factor_stored_forward_multiplied_backward(M, N, K, dtype):
+    dt = torch.float32 if dtype == "f32" else torch.bfloat16
+    p = 0.1
+    A, W, b = _data(M, N, K, 11 + M)
+    Ad, Wd = A.to(dt).to(DEV), W.to(dt).to(DEV)
+    lin = Ad.float().cpu().double() @ Wd.float().cpu().double().t() + b.double()
+    mask = HF.dropout_mask((M, N), 1234, p, DEV).cpu().double()
+    u, gp = HF.linear_nt(Ad, Wd, b.to(DEV), epi=HF.EPI_BIAS_GELU_DROP_G, epi_seed=1234, epi_p=p)
+    x = lin.clone().requires_grad_(True)
+    torch.nn.functional.gelu(x).sum().backward()
+    tol = 5e-5 if dtype == "f32" else 6e-3
+    assert rel_err(u.float().cpu(), torch.nn.functional.gelu(lin) * mask) < tol
+    assert rel_err(gp.float().cpu(), x.grad * mask) < tol
+    # the same pair as the older codes
+    u2, h1 = HF.linear_nt(Ad, Wd, b.to(DEV), epi=HF.EPI_BIAS_GELU_DROP, epi_seed=1234, epi_p=p)
+    assert rel_err(u.float().cpu(), u2.float().cpu().double()) < tol
+    dy = torch.randn(M, K, generator=torch.Generator().manual_seed(4)).to(dt).to(DEV)       # "A" = dY [M,K'], W [N,K']
+    got = HF.linear_nt(dy, Wd, None, epi=HF.EPI_MUL_AUX, aux=gp)
+    ref = (dy.float().cpu().double() @ Wd.float().cpu().double().t()) * gp.float().cpu().double()
+    assert rel_err(got.float().cpu(), ref) < tol
+    old = HF.linear_nt(dy, Wd, None, epi=HF.EPI_GELU_BWD, aux=h1, epi_seed=1234, epi_p=p)
+    assert rel_err(got.float().cpu(), old.float().cpu().double()) < (1e-4 if dtype == "f32" else 1.5e-2)
