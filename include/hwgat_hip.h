@@ -77,6 +77,14 @@ int hwgat_ln_bwd(const void* dy, const void* x, const float* mean, const float* 
                  const float* gamma, const void* dres, void* dx, float* dgamma, float* dbeta,
                  int64_t N, int d, int dtype, void* stream);
 
+/* The same, plus dx_masked = dx * dropout-mask(mask_seed, element index) with keep-scale 1/(1-mask_p): the masked
+ * gradient that the PRODUCER of this tensor needs in front of its Dropout (HWGATE.py:116,135 backward), written once
+ * here instead of being re-hashed in the GEMM loaders that consume it.  dres is required (the block's shortcut). */
+int hwgat_ln_bwd_masked(const void* dy, const void* x, const float* mean, const float* rstd,
+                        const float* gamma, const void* dres, void* dx, float* dgamma, float* dbeta,
+                        int64_t N, int d, int dtype, void* dx_masked, uint32_t mask_seed, float mask_p,
+                        void* stream);
+
 /* ---- a-4/a-5/a-6/a-10: fused window attention (MSA.forward, HWGATE.py:89-114)
  * over the body-part joint graph, with partition/roll/reverse as index math.
  *   qkv      (B, F, K, 3, nH, hd) `dtype` -- the qkv Linear output in natural

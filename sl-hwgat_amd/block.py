@@ -69,8 +69,12 @@ class _DwQueue:
 
 class _FusedBlock(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, thr, m1, r1, n1w, n1b, wqkv, bqkv, wp, bp, n2w, n2b, w1, b1, w2, b2, cfg):
-        bits, n_heads, shifted, p, seeds, kind, want_stats, merge_out = cfg
+    def forward(ctx, x, xc, thr, m1, r1, n1w, n1b, wqkv, bqkv, wp, bp, n2w, n2b, w1, b1, w2, b2, cfg):
+        # xc: the "carrier" the producing block handed over with x (or None).  It has no data (a 1-element tensor
+        # expanded to x's shape); its only purpose is that THIS block's backward can return, as its gradient, the masked
+        # copy of dx that the producing block needs in front of its fc2 dropout (cfg `up` = that dropout's seed).
+        bits, n_heads, shifted, p, seeds, kind, want_stats, merge_out, up, carry_out = cfg
+        ctx.set_materialize_grads(False)          # an unused carrier gradient arrives as None, not as a zero tensor
         B, F, K, d = x.shape
         dt = x.dtype                              # fp32, or bf16 activations with fp32 master weights
         cw = (lambda w: w) if dt == torch.float32 else (lambda w: w.to(dt))
@@ -97,13 +101,20 @@ class _FusedBlock(torch.autograd.Function):
         ctx.save_for_backward(x, thr, n1w, n1b, wqkv, wp, n2w, n2b, w1, w2, m1, r1, qkv, o, y, m2, r2, h1, u)
         ctx.cfg = cfg
         ctx.merged = merged
-        ctx.mark_non_differentiable(mo, ro)
-        return out, mo, ro
+        ctx.send_up = xc is not None and up is not None and p > 0.0
+        carry = bool(carry_out) and not merged and p > 0.0 and HF.MASK_ONCE >= 2
+        oc = x.new_zeros(1).expand(out.shape) if carry else x.new_empty(0)
+        if carry:
+            ctx.mark_non_differentiable(mo, ro)
+        else:
+            ctx.mark_non_differentiable(mo, ro, oc)
+        return out, mo, ro, oc
 
     @staticmethod
-    def backward(ctx, dout, _dmo, _dro):
+    def backward(ctx, dout, _dmo, _dro, doutm=None):
         x, thr, n1w, n1b, wqkv, wp, n2w, n2b, w1, w2, m1, r1, qkv, o, y, m2, r2, h1, u = ctx.saved_tensors
         bits, n_heads, shifted, p, seeds, kind = ctx.cfg[:6]
+        up = ctx.cfg[8]
         B, F, K, d = x.shape
         dt = x.dtype
         dout = dout.contiguous()
@@ -124,41 +135,67 @@ class _FusedBlock(torch.autograd.Function):
 
         dwq = _DwQueue(x.device, OVERLAP_DW)
         # ---- FFN branch: out = y + drop3(u W2^T + b2), u = drop2(gelu(h1)), h1 = LN2(y) W1^T + b1
-        dwq.run(lambda: HF.linear_tn(dout, u, dw2, db2, pro_seed=seeds[2], pro_p=p))
-        d_h1 = HF.linear_nt(dout, HF.transpose(w2, dt), None, pro=HF.PRO_DROP, pro_seed=seeds[2], pro_p=p,
-                            epi=HF.EPI_MUL_AUX, aux=h1)
+        if doutm is not None and not ctx.merged and doutm.shape == dout.shape:
+            # the consumer of this block's output already wrote dropmask3 * dout (hwgat_ln_bwd_masked): no hashing here
+            doutm = doutm.contiguous()
+            dwq.run(lambda: HF.linear_tn(doutm, u, dw2, db2))
+            d_h1 = HF.linear_nt(doutm, HF.transpose(w2, dt), None, epi=HF.EPI_MUL_AUX, aux=h1)
+        else:
+            dwq.run(lambda: HF.linear_tn(dout, u, dw2, db2, pro_seed=seeds[2], pro_p=p))
+            d_h1 = HF.linear_nt(dout, HF.transpose(w2, dt), None, pro=HF.PRO_DROP, pro_seed=seeds[2], pro_p=p,
+                                epi=HF.EPI_MUL_AUX, aux=h1)
         dwq.run(lambda: HF.linear_tn(d_h1, y, dw1, db1, ln=(m2, r2, n2w, n2b)))
         d_z = HF.linear_nt(d_h1, HF.transpose(w1, dt), None, epi=HF.EPI_NONE)
-        d_y = HF.ln_backward(d_z, y, m2, r2, n2w, dout, dn2w, dn2b)          # + shortcut gradient
         # ---- attention branch: y = x + drop1(o Wp^T + bp)
-        dwq.run(lambda: HF.linear_tn(d_y, o, dwp, dbp, pro_seed=seeds[0], pro_p=p))
-        d_o = HF.linear_nt(d_y, HF.transpose(wp, dt), None, pro=HF.PRO_DROP, pro_seed=seeds[0], pro_p=p,
-                           epi=HF.EPI_NONE, out=d_z)
+        if p > 0.0 and HF.MASK_ONCE >= 1:
+            d_y, d_ym = HF.ln_backward(d_z, y, m2, r2, n2w, dout, dn2w, dn2b, mask=(seeds[0], p))   # + shortcut; and dropmask1 * d_y
+            dwq.run(lambda: HF.linear_tn(d_ym, o, dwp, dbp))
+            d_o = HF.linear_nt(d_ym, HF.transpose(wp, dt), None, epi=HF.EPI_NONE, out=d_z)
+        else:
+            d_y = HF.ln_backward(d_z, y, m2, r2, n2w, dout, dn2w, dn2b)          # + shortcut gradient
+            dwq.run(lambda: HF.linear_tn(d_y, o, dwp, dbp, pro_seed=seeds[0], pro_p=p))
+            d_o = HF.linear_nt(d_y, HF.transpose(wp, dt), None, pro=HF.PRO_DROP, pro_seed=seeds[0], pro_p=p,
+                               epi=HF.EPI_NONE, out=d_z)
         dqkv = torch.empty_like(qkv)
         HF.attn_bwd(kind, qkv, d_o, dqkv, bits, thr, n_heads, shifted)
         dwq.run(lambda: HF.linear_tn(dqkv, x, dwqkv, dbqkv, ln=(m1, r1, n1w, n1b)))
         d_xn = HF.linear_nt(dqkv, HF.transpose(wqkv, dt), None, epi=HF.EPI_NONE, out=d_o)
         # (the first block's input comes from the parameter-free embedding: its dx is still produced because
         # dgamma / dbeta of norm1 fall out of the same LayerNorm-backward pass)
-        dx = HF.ln_backward(d_xn, x, m1, r1, n1w, d_y, dn1w, dn1b)
+        dxm = None
+        if ctx.send_up:           # the block that produced x gets dropmask3(its seed) * dx through the carrier's gradient
+            dx, dxm = HF.ln_backward(d_xn, x, m1, r1, n1w, d_y, dn1w, dn1b, mask=up)
+        else:
+            dx = HF.ln_backward(d_xn, x, m1, r1, n1w, d_y, dn1w, dn1b)
         dwq.join()        # every temporary above stays referenced until here, so the allocator cannot recycle it early
-        return (dx, None, None, None, dn1w, dn1b, dwqkv, dbqkv, dwp, dbp, dn2w, dn2b, dw1, db1, dw2, db2, None)
+        return (dx, dxm, None, None, None, dn1w, dn1b, dwqkv, dbqkv, dwp, dbp, dn2w, dn2b, dw1, db1, dw2, db2, None)
 
 
 def fused_block(x, thr, blk, bits, n_heads, shifted, p, seeds, kind="win", stats=None, want_stats=False,
-                merge_out=False, return_stats=False):
+                merge_out=False, return_stats=False, carrier=None, up=None, carry_out=False, return_carrier=None):
     """x (B,F,K,d) contiguous; `blk` holds norm1/attn.qkv/attn.proj/norm2/ff.fc1/ff.fc2.
     `kind`: 'win' = HWGATE part-window attention, 'blk' = HGATE block attention (thr must be None).
     `stats` = (mean, rstd) of the rows of x if the producer already has them; `want_stats`: have the fc2 epilogue produce
     the statistics of the output rows; `merge_out`: store the output in the TemporalMerging layout (B, F/2, K, 2d)
     (done only where the epilogue can: fp32, whole tiles -- check the returned shape).
-    Returns out, or (out, (mean, rstd) or None) with `return_stats`."""
+    `carrier` / `up` / `carry_out` (training with dropout): the dropout mask of a block's fc2 output is applied to the
+    incoming gradient ONCE, by the LayerNorm backward of the block that consumes that output, instead of in two GEMM
+    loaders: `carry_out` makes this block return a data-less carrier next to `out`; the consumer passes it as `carrier`
+    together with `up` = (this block's seeds[2], p) and returns the masked gradient as the carrier's gradient.
+    Returns out, or (out, (mean, rstd) or None) with `return_stats`; with `carry_out` / `return_carrier` the carrier (or None) is appended."""
     m1, r1 = stats if stats is not None else (None, None)
-    out, mo, ro = _FusedBlock.apply(
-        x, thr, m1, r1, blk.norm1.weight, blk.norm1.bias, blk.attn.qkv.weight, blk.attn.qkv.bias,
+    if carrier is not None and (carrier.shape != x.shape or not x.requires_grad):
+        carrier = None
+    out, mo, ro, oc = _FusedBlock.apply(
+        x, carrier, thr, m1, r1, blk.norm1.weight, blk.norm1.bias, blk.attn.qkv.weight, blk.attn.qkv.bias,
         blk.attn.proj.weight, blk.attn.proj.bias, blk.norm2.weight, blk.norm2.bias,
         blk.ff.fc1.weight, blk.ff.fc1.bias, blk.ff.fc2.weight, blk.ff.fc2.bias,
-        (bits, n_heads, shifted, float(p), tuple(int(s) for s in seeds), kind, bool(want_stats), bool(merge_out)))
+        (bits, n_heads, shifted, float(p), tuple(int(s) for s in seeds), kind, bool(want_stats), bool(merge_out),
+         (int(up[0]), float(up[1])) if (up is not None and carrier is not None) else None, bool(carry_out)))
+    oc = oc if oc.numel() else None
+    if return_carrier is None:
+        return_carrier = bool(carry_out)
     if not return_stats:
-        return out
-    return out, ((mo, ro) if mo.numel() else None)
+        return (out, oc) if return_carrier else out
+    st = (mo, ro) if mo.numel() else None
+    return (out, st, oc) if return_carrier else (out, st)

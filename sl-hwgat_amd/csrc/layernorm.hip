@@ -8,6 +8,7 @@
 // chunks, so every global access is a full 16 B/lane coalesced vector; statistics
 // are two-pass in registers (mean, then centred variance) in fp32.
 #include "common.h"
+#include "fused_ops.h"
 
 namespace {
 
@@ -87,13 +88,18 @@ __global__ __launch_bounds__(256) void ln_fwd_k(const T* __restrict__ x, const f
 
 // ------------------------------------------------------------------ backward
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma
-template <typename T, int D, bool RES>
+// MASK: also write dxm = dx * dropout-keep(seed, element index) -- the gradient this tensor's PRODUCER needs in front of
+// its dropout (dX and dW of the linear whose output was dropped).  The hash is evaluated once here, in an HBM-bound
+// kernel whose vector units idle, instead of in every tile of the two GEMM loaders that consume the masked gradient
+// (8 evaluations per element at stage 2, none of them hidden behind the MFMAs).
+template <typename T, int D, bool RES, bool MASK>
 __global__ __launch_bounds__(256) void ln_bwd_k(const T* __restrict__ dy, const T* __restrict__ x,
                                                 const float* __restrict__ mean_i,
                                                 const float* __restrict__ rstd_i,
                                                 const float* __restrict__ gamma, const T* __restrict__ dres,
                                                 T* __restrict__ dx, float* __restrict__ dgamma,
-                                                float* __restrict__ dbeta, int64_t N) {
+                                                float* __restrict__ dbeta, int64_t N, T* __restrict__ dxm,
+                                                uint32_t mseed, float mp) {
     using M = RowMap<D>;
     __shared__ float red[2][4][D];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -143,6 +149,16 @@ __global__ __launch_bounds__(256) void ln_bwd_k(const T* __restrict__ dy, const 
                 for (int e = 0; e < 4; ++e) dv[c][e] = rstd * (dv[c][e] - s1 - xv[c][e] * s2);
         }
         store_row<T, D>(dx + r * D, sub, dv);
+        if constexpr (MASK) {
+            const uint32_t th = drop_thresh(mp);
+            const float sc = 1.0f / (1.0f - mp);
+#pragma unroll
+            for (int c = 0; c < M::CPL; ++c) {
+                const f32x4 k = drop_keep4(mseed, (uint64_t)(r * D + (c * M::LPR + sub) * 4), th, sc);
+                dv[c][0] *= k.x; dv[c][1] *= k.y; dv[c][2] *= k.z; dv[c][3] *= k.w;
+            }
+            store_row<T, D>(dxm + r * D, sub, dv);
+        }
     }
     // fold the RPW row groups of a wave, then the 4 waves, then one atomic per column per block
     if constexpr (M::RPW == 2) {
@@ -275,12 +291,14 @@ int ln_fwd_t(const void* x, const float* gm, const float* bt, void* y, float* me
 #undef GO
     HWGAT_LAUNCH_CHECK();
 }
-template <typename T, bool RES>
+template <typename T, bool RES, bool MASK = false>
 int ln_bwd_t(const void* dy, const void* x, const float* mean, const float* rstd, const float* gm,
-             const void* dres, void* dx, float* dg, float* db, int64_t N, int d, hipStream_t st) {
-#define GO(D)                                                                                              \
-    ln_bwd_k<T, D, RES><<<(ln_grid(N, RowMap<D>::RPW) < 1024 ? ln_grid(N, RowMap<D>::RPW) : 1024), 256, 0, \
-                          st>>>((const T*)dy, (const T*)x, mean, rstd, gm, (const T*)dres, (T*)dx, dg, db, N)
+             const void* dres, void* dx, float* dg, float* db, int64_t N, int d, hipStream_t st,
+             void* dxm = nullptr, uint32_t mseed = 0, float mp = 0.f) {
+#define GO(D)                                                                                                    \
+    ln_bwd_k<T, D, RES, MASK><<<(ln_grid(N, RowMap<D>::RPW) < 1024 ? ln_grid(N, RowMap<D>::RPW) : 1024), 256, 0, \
+                                st>>>((const T*)dy, (const T*)x, mean, rstd, gm, (const T*)dres, (T*)dx, dg, db, \
+                                      N, (T*)dxm, mseed, mp)
     switch (d) {
         case 128: GO(128); break;
         case 256: GO(256); break;
@@ -375,6 +393,20 @@ extern "C" int hwgat_ln_bwd(const void* dy, const void* x, const float* mean, co
     if (dtype == HWGAT_BF16)
         return dres ? ln_bwd_t<bf16_t, true>(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, N, d, st)
                     : ln_bwd_t<bf16_t, false>(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, N, d, st);
+    return HWGAT_EDTYPE;
+}
+
+extern "C" int hwgat_ln_bwd_masked(const void* dy, const void* x, const float* mean, const float* rstd,
+                                   const float* gamma, const void* dres, void* dx, float* dgamma, float* dbeta,
+                                   int64_t N, int d, int dtype, void* dx_masked, uint32_t mask_seed, float mask_p,
+                                   void* stream) {
+    if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || !dres || !dx_masked || N <= 0) return HWGAT_EINVAL;
+    if (mask_p <= 0.f || mask_p >= 1.f) return HWGAT_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == HWGAT_F32)
+        return ln_bwd_t<float, true, true>(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, N, d, st, dx_masked, mask_seed, mask_p);
+    if (dtype == HWGAT_BF16)
+        return ln_bwd_t<bf16_t, true, true>(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, N, d, st, dx_masked, mask_seed, mask_p);
     return HWGAT_EDTYPE;
 }
 

@@ -331,6 +331,10 @@ PRO_NONE, PRO_LN, PRO_DROP, PRO_LN_FOLD = 0, 1, 2, 3
 # the GEMM epilogue (hwgat_ln_fold + pro 3) when the token count is whole tiles; HWGAT_LN_FOLD=0 keeps the
 # in-kernel normalising loader (pro 1) everywhere.
 LN_FOLD = os.environ.get("HWGAT_LN_FOLD", "1") != "0"
+# Dropout masks in the backward pass: 0 = hashed in every GEMM loader that needs the masked gradient; 1 = the
+# LayerNorm backward that produces a gradient also writes its masked copy once (hwgat_ln_bwd_masked) for the block's own
+# projection dropout; 2 (default) = also across blocks, for the fc2 dropout of the block that produced this block's input.
+MASK_ONCE = int(os.environ.get("HWGAT_MASK_ONCE", "2"))
 EPI_BIAS, EPI_BIAS_DROP_RES, EPI_BIAS_GELU_DROP, EPI_GELU_BWD, EPI_NONE, EPI_BIAS_GELU_DROP_G, EPI_MUL_AUX = 0, 1, 2, 3, 4, 5, 6
 
 
@@ -395,7 +399,7 @@ def linear_nt_ln(A, W, bias, ln, *, epi=EPI_BIAS, epi_seed=0, epi_p=0.0, out=Non
     normalisation in the GEMM's load path), anything else the normalising loader."""
     mean, rstd, gamma, beta = ln
     M = A.numel() // A.shape[-1]
-    if LN_FOLD and M % 128 == 0:
+    if LN_FOLD and M % 128 == 0 and W.dtype == torch.float32 and gamma.dtype == torch.float32:   # hwgat_ln_fold reads fp32 masters
         Wf, s, c = ln_fold(W, bias, gamma, beta, A.dtype)
         return linear_nt(A, Wf, None, pro=PRO_LN_FOLD, ln=(mean, rstd, s, c), epi=epi, epi_seed=epi_seed, epi_p=epi_p, out=out)
     Wc = W if W.dtype == A.dtype else W.to(A.dtype)
@@ -422,10 +426,16 @@ def ln_stats(x, gamma, beta):
     return mean, rstd
 
 
-def ln_backward(dy, x, mean, rstd, gamma, dres, dgamma, dbeta):
-    """dx = dLN(dy) (+ dres); dgamma/dbeta accumulated in place"""
+def ln_backward(dy, x, mean, rstd, gamma, dres, dgamma, dbeta, mask=None):
+    """dx = dLN(dy) (+ dres); dgamma/dbeta accumulated in place.  mask = (seed, p): also returns dx * dropout-mask
+    (the gradient in front of the dropout that produced this tensor) -> (dx, dx_masked)."""
     d = x.shape[-1]
     dx = torch.empty_like(x)
+    if mask is not None:
+        dxm = torch.empty_like(x)
+        call("hwgat_ln_bwd_masked", ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(dres), ptr(dx),
+             ptr(dgamma), ptr(dbeta), x.numel() // d, d, dtype_code(x), ptr(dxm), mask[0] & 0xFFFFFFFF, float(mask[1]), stream())
+        return dx, dxm
     call("hwgat_ln_bwd", ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(dres), ptr(dx),
          ptr(dgamma), ptr(dbeta), x.numel() // d, d, dtype_code(x), stream())
     return dx

@@ -173,9 +173,15 @@ class Model(nn.Module):
             rs = getattr(self, "_row_stats", None)
             have = rs[1] if (rs is not None and rs[0] is h) else None
             want, merge = getattr(self, "_plan", {}).get(k, (False, False))
-            out, st = fused_block(h, thr, blk, self._mask_bits, n_heads, shifted, p, self._seeds(k), self._attn_kind,
-                                  stats=have, want_stats=want, merge_out=merge, return_stats=True)
+            # carrier of the dropout-masked gradient between consecutive blocks of a stage (block.fused_block)
+            cr = getattr(self, "_carrier", None)
+            carrier, up = (cr[1], cr[2]) if (cr is not None and cr[0] is h) else (None, None)
+            seeds = self._seeds(k)
+            out, st, oc = fused_block(h, thr, blk, self._mask_bits, n_heads, shifted, p, seeds, self._attn_kind,
+                                      stats=have, want_stats=want, merge_out=merge, return_stats=True,
+                                      carrier=carrier, up=up, carry_out=want and not merge, return_carrier=True)
             self._row_stats = (out, st) if st is not None else None
+            self._carrier = (out, oc, (seeds[2], p)) if oc is not None else None
             return out
         xn = HF.layer_norm(h, blk.norm1.weight, blk.norm1.bias)
         qkv = self._linear(xn, blk.attn.qkv)
@@ -207,6 +213,7 @@ class Model(nn.Module):
         k = 0
         n_blocks = sum(len(st.blocks) for st in self.layers)
         self._row_stats = None
+        self._carrier = None
         self._plan, kk = {}, 0
         for i, stage in enumerate(self.layers):          # every block but the last feeds a LayerNorm; stage ends merge
             for j in range(len(stage.blocks)):
@@ -225,6 +232,7 @@ class Model(nn.Module):
             if i < self.num_layers - 1 and h.shape[-1] == self.embed_dim * 2 ** i:
                 h = HF.temporal_merge(h)                  # the fc2 epilogue could not store merged (bf16 / ragged M)
         self._row_stats = None
+        self._carrier = None
         return HF.ln_mean_pool(h, self.norm.weight, self.norm.bias)
 
     def forward(self, x):

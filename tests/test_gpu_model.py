@@ -220,6 +220,53 @@ def test_fused_dropout_matches_unfused_math_with_same_masks():
         assert rel_err(grads[n].cpu(), q.grad.cpu()) < 1e-4, n
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_dropout_mask_applied_once_by_the_consumer_equals_hashing_in_the_loaders(dtype):
+    """train mode, drop 0.1, two consecutive blocks of a stage: the path where the LayerNorm backward of the consuming
+    block writes dropmask * dx once (carrier gradient, hwgat_ln_bwd_masked) against the path that hashes the masks in the
+    GEMM loaders -- same masks, so the same gradients up to summation order; and both against torch ops with those masks."""
+    torch.manual_seed(7)
+    dt = torch.float32 if dtype == "f32" else torch.bfloat16
+    B, F, K, d, nH, p = 2, 8, 32, 128, 2, 0.1                 # M = 512 rows: whole tiles, epilogue statistics on
+    hp = hw.HWGATEParams({"src_len": 16, "num_class": 3}, 2, DEV, num_kps=K)
+    model = hw.Model(*hp.get_model_params()).to(DEV)
+    blks = [model.layers[0].blocks[0], model.layers[0].blocks[1]]
+    for b in blks:
+        for prm in b.parameters():
+            prm.data.normal_(0, 0.1)
+    from importlib import import_module
+    fb = import_module("sl-hwgat_amd.block")
+    HF = hw.functional
+    x0 = torch.randn(B, F, K, d, device=DEV).to(dt)
+    thr = torch.tensor([0.2], device=DEV)
+    s0, s1 = [11, 22, 33], [44, 55, 66]
+    g = None
+    results = []
+    saved = HF.MASK_ONCE
+    try:
+        for mode in (0, 2):
+            HF.MASK_ONCE = mode
+            x = x0.clone().requires_grad_(True)
+            h, st, oc = fb.fused_block(x, thr, blks[0], model._mask_bits, nH, False, p, s0, want_stats=True,
+                                       return_stats=True, carry_out=True)
+            assert (oc is not None) == (mode == 2)
+            out = fb.fused_block(h, thr, blks[1], model._mask_bits, nH, True, p, s1, stats=st, carrier=oc, up=(s0[2], p))
+            if g is None:
+                g = torch.randn_like(out)
+            out.backward(g)
+            results.append((out.detach().float().cpu(), x.grad.float().cpu(),
+                            {f"{i}.{n}": q.grad.clone().cpu() for i, b in enumerate(blks) for n, q in b.named_parameters()}))
+            for b in blks:
+                for q in b.parameters():
+                    q.grad = None
+    finally:
+        HF.MASK_ONCE = saved
+    tol = 2e-5 if dtype == "f32" else 1.5e-2
+    (o0, gx0, gp0), (o2, gx2, gp2) = results
+    assert rel_err(o2, o0.double()) < (1e-6 if dtype == "f32" else 1e-2)   # the forward is the same code (row statistics: atomics)
+    assert rel_err(gx2, gx0.double()) < tol
+    for n in gp0:
+        assert rel_err(gp2[n], gp0[n].double()) < tol, n
 def test_micro_batched_step_equals_full_batch_step():
     from importlib import import_module
     tr = import_module("sl-hwgat_amd.train")

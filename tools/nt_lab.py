@@ -43,7 +43,8 @@ for i in stages:
     res, aux = act(M, d), act(M, 2 * d)
     gamma, beta = rnd(d), rnd(d)
     mean, rstd = HF.ln_stats(x, gamma, beta)
-    w_qkv, w_p, w1, w2 = ((rnd(*s) * .05).to(dt) for s in ((3 * d, d), (d, d), (2 * d, d), (d, 2 * d)))
+    w_qkv32, w_p32, w1_32, w2_32 = (rnd(*s) * .05 for s in ((3 * d, d), (d, d), (2 * d, d), (d, 2 * d)))     # fp32 masters
+    w_qkv, w_p, w1, w2 = (w.to(dt) for w in (w_qkv32, w_p32, w1_32, w2_32))
     w_qkv_t, w_p_t, w1_t, w2_t = (w.t().contiguous() for w in (w_qkv, w_p, w1, w2))
     b3, b1, b2 = rnd(3 * d), rnd(d), rnd(2 * d)
     o3, o1, o2, o2b = (torch.empty(M, 3 * d, device=dev, dtype=dt), torch.empty(M, d, device=dev, dtype=dt),
@@ -51,11 +52,11 @@ for i in stages:
     esz = 2 if dt == torch.bfloat16 else 4
     ln = (mean, rstd, gamma, beta)
     cases = [
-        ("qkv   LN -> bias         ", M, 3 * d, d, lambda: HF.linear_nt(x, w_qkv, b3, pro=HF.PRO_LN, ln=ln, out=o3)),
+        ("qkv   LN(folded) -> bias ", M, 3 * d, d, lambda: HF.linear_nt_ln(x, w_qkv32, b3, ln, out=o3)),
         ("proj  bias+drop+res      ", M, d, d, lambda: HF.linear_nt(x, w_p, b1, epi=HF.EPI_BIAS_DROP_RES, res=res, epi_seed=1, epi_p=.1, out=o1)),
-        ("fc1   LN -> bias+gelu+drop", M, 2 * d, d, lambda: HF.linear_nt(x, w1, b2, pro=HF.PRO_LN, ln=ln, epi=HF.EPI_BIAS_GELU_DROP, epi_seed=2, epi_p=.1, out=o2)),
+        ("fc1   LN(folded) -> bias+gelu+drop, gelu' saved", M, 2 * d, d, lambda: HF.linear_nt_ln(x, w1_32, b2, ln, epi=HF.EPI_BIAS_GELU_DROP_G, epi_seed=2, epi_p=.1, out=o2)),
         ("fc2   bias+drop+res      ", M, d, 2 * d, lambda: HF.linear_nt(u2, w2, b1, epi=HF.EPI_BIAS_DROP_RES, res=res, epi_seed=3, epi_p=.1, out=o1)),
-        ("d_h1  drop -> gelu-bwd   ", M, 2 * d, d, lambda: HF.linear_nt(x, w2_t, None, pro=HF.PRO_DROP, pro_seed=3, pro_p=.1, epi=HF.EPI_GELU_BWD, aux=aux, epi_seed=2, epi_p=.1, out=o2)),
+        ("d_h1  drop -> x gelu'    ", M, 2 * d, d, lambda: HF.linear_nt(x, w2_t, None, pro=HF.PRO_DROP, pro_seed=3, pro_p=.1, epi=HF.EPI_MUL_AUX, aux=aux, out=o2)),
         ("d_z   plain              ", M, d, 2 * d, lambda: HF.linear_nt(u2, w1_t, None, epi=HF.EPI_NONE, out=o1)),
         ("d_o   drop -> plain      ", M, d, d, lambda: HF.linear_nt(x, w_p_t, None, pro=HF.PRO_DROP, pro_seed=1, pro_p=.1, epi=HF.EPI_NONE, out=o1)),
         ("d_xn  plain              ", M, d, 3 * d, lambda: HF.linear_nt(y3, w_qkv_t, None, epi=HF.EPI_NONE, out=o1)),
@@ -68,6 +69,9 @@ for i in stages:
         ]
     if os.environ.get("NT_LAB_ABLATE") == "1":     # what each prologue / epilogue costs: the same shapes with pieces removed
         cases += [
+            ("qkv   LN in the loader (pro 1)", M, 3 * d, d, lambda: HF.linear_nt(x, w_qkv, b3, pro=HF.PRO_LN, ln=ln, out=o3)),
+            ("fc1   LN in the loader, pre-activation saved (epi 2)", M, 2 * d, d, lambda: HF.linear_nt(x, w1, b2, pro=HF.PRO_LN, ln=ln, epi=HF.EPI_BIAS_GELU_DROP, epi_seed=2, epi_p=.1, out=o2)),
+            ("d_h1  drop -> gelu-bwd (epi 3)", M, 2 * d, d, lambda: HF.linear_nt(x, w2_t, None, pro=HF.PRO_DROP, pro_seed=3, pro_p=.1, epi=HF.EPI_GELU_BWD, aux=aux, epi_seed=2, epi_p=.1, out=o2)),
             ("qkv   (no LN) bias        ", M, 3 * d, d, lambda: HF.linear_nt(x, w_qkv, b3, out=o3)),
             ("fc1   LN -> bias only     ", M, 2 * d, d, lambda: HF.linear_nt(x, w1, b2, pro=HF.PRO_LN, ln=ln, out=o2)),
             ("fc1   (no LN) gelu+drop   ", M, 2 * d, d, lambda: HF.linear_nt(x, w1, b2, epi=HF.EPI_BIAS_GELU_DROP, epi_seed=2, epi_p=.1, out=o2)),
@@ -81,7 +85,8 @@ for i in stages:
     for name, m, n, k, fn in cases:
         t = bench(fn)
         fl = 2.0 * m * n * k
-        extra = "statistics" in name or "(no" in name or "only" in name or "p=0" in name or name.startswith("d_h1  drop -> plain")
+        extra = ("statistics" in name or "(no" in name or "only" in name or "p=0" in name or name.startswith("d_h1  drop -> plain")
+                 or "(pro 1)" in name or "(epi 2)" in name or "(epi 3)" in name)
         if not extra:
             total += t * depth
         if extra and "statistics" not in name:
