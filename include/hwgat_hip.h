@@ -159,11 +159,19 @@ int hwgat_lnpool_fwd(const void* x, float* xhat_sum, float* mean, float* rstd,
 /* backward: g (B, d) fp32 = dfeat * gamma / n_tok  ->  dx (B, n_tok, d) */
 int hwgat_lnpool_bwd(const float* g, const void* x, const float* mean, const float* rstd,
                      void* dx, int B, int n_tok, int d, int dtype, void* stream);
+/* ... and dx_masked = dx * dropout-mask(mask_seed, element index), see hwgat_ln_bwd_masked (dx_masked may be NULL) */
+int hwgat_lnpool_bwd_masked(const float* g, const void* x, const float* mean, const float* rstd,
+                            void* dx, int B, int n_tok, int d, int dtype, void* dx_masked, uint32_t mask_seed,
+                            float mask_p, void* stream);
 
 /* ---- a-9: TemporalMerging (HWGATE.py:55-63): (B,F,K,d) -> (B,F/2,K,2d),
  * out[b,fi,k,tp*d+c] = in[b,2fi+tp,k,c]; `inverse` = 1 maps gradients back. */
 int hwgat_merge(const void* in, void* out, int B, int F, int K, int d, int inverse,
                 int dtype, void* stream);
+/* inverse mapping of a gradient plus a second, dropout-masked copy (mask of (mask_seed, un-merged element index)):
+ * what the last block of a stage needs in front of its fc2 Dropout (HWGATE.py:135 backward) */
+int hwgat_unmerge_masked(const void* in, void* out, void* out_masked, int B, int F, int K, int d, int dtype,
+                         uint32_t mask_seed, float mask_p, void* stream);
 
 /* ---- a-6/a-7/a-8: fp32 Linear layers on f32 MFMA with fused elementwise work.
  * Replaces nn.Linear (HWGATE.py:86,115,131,134) + bias + GELU (:132) + Dropout

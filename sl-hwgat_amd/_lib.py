@@ -37,6 +37,8 @@ _SIGS = {
     "hwgat_debug_mfma16x16x4": [_P, _P, _P, _P],
     "hwgat_lnpool_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "hwgat_lnpool_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "hwgat_lnpool_bwd_masked": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _U, _F, _P],
+    "hwgat_unmerge_masked": [_P, _P, _P, _I, _I, _I, _I, _I, _U, _F, _P],
     "hwgat_merge": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "hwgat_linear_nt_f32": [_P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _P, _U, _F, _I, _P, _P, _P, _U, _F, _P],
     "hwgat_linear_nt_f32_ex": [_P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _P, _U, _F, _I, _P, _P, _P, _U, _F, _P, _P, _I, _I, _P],

@@ -120,7 +120,13 @@ class _FusedBlock(torch.autograd.Function):
         dout = dout.contiguous()
         if ctx.merged:                            # the gradient arrives in the merged layout: back to (B, F, K, d)
             nat = torch.empty_like(x)
-            HF.call("hwgat_merge", HF.ptr(dout), HF.ptr(nat), B, F, K, d, 1, HF.dtype_code(dout), HF.stream())
+            if p > 0.0 and HF.MASK_ONCE >= 2:     # ... and once more multiplied by this block's fc2-dropout mask
+                doutm = torch.empty_like(x)
+                HF.call("hwgat_unmerge_masked", HF.ptr(dout), HF.ptr(nat), HF.ptr(doutm), B, F, K, d, HF.dtype_code(dout),
+                        seeds[2] & 0xFFFFFFFF, float(p), HF.stream())
+            else:
+                doutm = None
+                HF.call("hwgat_merge", HF.ptr(dout), HF.ptr(nat), B, F, K, d, 1, HF.dtype_code(dout), HF.stream())
             dout = nat
         # all 12 parameter gradients are accumulated into (split-M atomics, LN column sums): one flat
         # zero-filled buffer and views of it instead of 12 fill launches
@@ -135,7 +141,7 @@ class _FusedBlock(torch.autograd.Function):
 
         dwq = _DwQueue(x.device, OVERLAP_DW)
         # ---- FFN branch: out = y + drop3(u W2^T + b2), u = drop2(gelu(h1)), h1 = LN2(y) W1^T + b1
-        if doutm is not None and not ctx.merged and doutm.shape == dout.shape:
+        if doutm is not None and doutm.shape == dout.shape:
             # the consumer of this block's output already wrote dropmask3 * dout (hwgat_ln_bwd_masked): no hashing here
             doutm = doutm.contiguous()
             dwq.run(lambda: HF.linear_tn(doutm, u, dw2, db2))

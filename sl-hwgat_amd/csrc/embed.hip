@@ -57,9 +57,12 @@ __global__ __launch_bounds__(256) void embed_fwd_k(const float* __restrict__ x, 
 }
 
 // 16-byte chunks; forward: out[b,fi,k,tp*d+c] = in[b,2fi+tp,k,c]
+// out_m (inverse only): a second copy multiplied by the dropout mask of (seed, un-merged element index) -- the gradient of
+// a stage's last block arrives merged; its fc2-dropout backward needs the masked un-merged gradient (see ln_bwd_k<MASK>)
 template <typename T>
 __global__ __launch_bounds__(256) void merge_k(const T* __restrict__ in, T* __restrict__ out, int64_t n_chunks,
-                                               int F, int K, int d, int inverse) {
+                                               int F, int K, int d, int inverse, T* __restrict__ out_m = nullptr,
+                                               uint32_t mseed = 0, float mp = 0.f) {
     constexpr int EPV = io<T>::EPV;
     const int cpr = d / EPV;                                   // chunks per input row
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -73,7 +76,35 @@ __global__ __launch_bounds__(256) void merge_k(const T* __restrict__ in, T* __re
         const int64_t j = (((b * (F / 2) + (fr >> 1)) * K + k) * 2 + (fr & 1)) * cpr + c;
         const u32x4* src = reinterpret_cast<const u32x4*>(in);
         u32x4* dst = reinterpret_cast<u32x4*>(out);
-        if (inverse) dst[i] = src[j]; else dst[j] = src[i];
+        if (inverse) {
+            const u32x4 v = src[j];
+            dst[i] = v;
+            if (out_m != nullptr) {
+                const uint32_t th = drop_thresh(mp);
+                const float sc = 1.0f / (1.0f - mp);
+                u32x4 w = v;
+                if constexpr (EPV == 4) {
+                    const f32x4 k = drop_keep4(mseed, (uint64_t)i * 4, th, sc);
+                    w.x = __float_as_uint(__uint_as_float(v.x) * k.x); w.y = __float_as_uint(__uint_as_float(v.y) * k.y);
+                    w.z = __float_as_uint(__uint_as_float(v.z) * k.z); w.w = __float_as_uint(__uint_as_float(v.w) * k.w);
+                } else {
+                    const f32x4 k0 = drop_keep4(mseed, (uint64_t)i * 8, th, sc), k1 = drop_keep4(mseed, (uint64_t)i * 8 + 4, th, sc);
+                    const uint32_t r4[4] = {v.x, v.y, v.z, v.w};
+                    const float kk[8] = {k0.x, k0.y, k0.z, k0.w, k1.x, k1.y, k1.z, k1.w};
+                    uint32_t o4[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const bf16_t lo = (bf16_t)(__uint_as_float(r4[q] << 16) * kk[2 * q]);
+                        const bf16_t hi = (bf16_t)(__uint_as_float(r4[q] & 0xffff0000u) * kk[2 * q + 1]);
+                        o4[q] = (uint32_t)__builtin_bit_cast(uint16_t, lo) | ((uint32_t)__builtin_bit_cast(uint16_t, hi) << 16);
+                    }
+                    w.x = o4[0]; w.y = o4[1]; w.z = o4[2]; w.w = o4[3];
+                }
+                reinterpret_cast<u32x4*>(out_m)[i] = w;
+            }
+        } else {
+            dst[j] = src[i];
+        }
     }
 }
 
@@ -107,6 +138,22 @@ extern "C" int hwgat_merge(const void* in, void* out, int B, int F, int K, int d
     const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
     if (dtype == HWGAT_F32) merge_k<float><<<grid, 256, 0, st>>>((const float*)in, (float*)out, n, F, K, d, inverse);
     else merge_k<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)in, (bf16_t*)out, n, F, K, d, inverse);
+    HWGAT_LAUNCH_CHECK();
+}
+
+extern "C" int hwgat_unmerge_masked(const void* in, void* out, void* out_masked, int B, int F, int K, int d, int dtype,
+                                    uint32_t mask_seed, float mask_p, void* stream) {
+    if (!in || !out || !out_masked || B <= 0 || F <= 0 || K <= 0 || d <= 0) return HWGAT_EINVAL;
+    if (mask_p <= 0.f || mask_p >= 1.f) return HWGAT_EINVAL;
+    if (F & 1) return HWGAT_ESHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype != HWGAT_F32 && dtype != HWGAT_BF16) return HWGAT_EDTYPE;
+    const int epv = dtype == HWGAT_F32 ? 4 : 8;
+    if (d % epv) return HWGAT_ESHAPE;
+    const int64_t n = (int64_t)B * F * K * (d / epv);
+    const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    if (dtype == HWGAT_F32) merge_k<float><<<grid, 256, 0, st>>>((const float*)in, (float*)out, n, F, K, d, 1, (float*)out_masked, mask_seed, mask_p);
+    else merge_k<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)in, (bf16_t*)out, n, F, K, d, 1, (bf16_t*)out_masked, mask_seed, mask_p);
     HWGAT_LAUNCH_CHECK();
 }
 

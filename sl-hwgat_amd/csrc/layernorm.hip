@@ -238,7 +238,8 @@ template <typename T, int D>
 __global__ __launch_bounds__(256) void lnpool_bwd_k(const float* __restrict__ g, const T* __restrict__ x,
                                                     const float* __restrict__ mean_i,
                                                     const float* __restrict__ rstd_i, T* __restrict__ dx,
-                                                    int n_tok, int chunks) {
+                                                    int n_tok, int chunks, T* __restrict__ dxm, uint32_t mseed,
+                                                    float mp) {
     using M = RowMap<D>;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int sub = lane % M::LPR, rsub = lane / M::LPR;
@@ -269,6 +270,16 @@ __global__ __launch_bounds__(256) void lnpool_bwd_k(const float* __restrict__ g,
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[c][e] = rstd * (gv[c][e] - s1 - v[c][e] * s2);
         store_row<T, D>(dx + r * D, sub, v);
+        if (dxm != nullptr) {                                   // see ln_bwd_k<.., MASK>
+            const uint32_t th = drop_thresh(mp);
+            const float sc = 1.0f / (1.0f - mp);
+#pragma unroll
+            for (int c = 0; c < M::CPL; ++c) {
+                const f32x4 k = drop_keep4(mseed, (uint64_t)(r * D + (c * M::LPR + sub) * 4), th, sc);
+                v[c][0] *= k.x; v[c][1] *= k.y; v[c][2] *= k.z; v[c][3] *= k.w;
+            }
+            store_row<T, D>(dxm + r * D, sub, v);
+        }
     }
 }
 
@@ -431,12 +442,23 @@ extern "C" int hwgat_lnpool_fwd(const void* x, float* xhat_sum, float* mean, flo
     HWGAT_LAUNCH_CHECK();
 }
 
+extern "C" int hwgat_lnpool_bwd_masked(const float* g, const void* x, const float* mean, const float* rstd, void* dx,
+                                       int B, int n_tok, int d, int dtype, void* dx_masked, uint32_t mask_seed,
+                                       float mask_p, void* stream);
+
 extern "C" int hwgat_lnpool_bwd(const float* g, const void* x, const float* mean, const float* rstd, void* dx,
                                 int B, int n_tok, int d, int dtype, void* stream) {
+    return hwgat_lnpool_bwd_masked(g, x, mean, rstd, dx, B, n_tok, d, dtype, nullptr, 0, 0.f, stream);
+}
+
+extern "C" int hwgat_lnpool_bwd_masked(const float* g, const void* x, const float* mean, const float* rstd, void* dx,
+                                       int B, int n_tok, int d, int dtype, void* dxm, uint32_t mseed, float mp,
+                                       void* stream) {
     if (!g || !x || !mean || !rstd || !dx || B <= 0 || n_tok <= 0) return HWGAT_EINVAL;
+    if (dxm && (mp <= 0.f || mp >= 1.f)) return HWGAT_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int ch = pool_chunks(B, n_tok);
-#define GO(T, D) lnpool_bwd_k<T, D><<<B * ch, 256, 0, st>>>(g, (const T*)x, mean, rstd, (T*)dx, n_tok, ch)
+#define GO(T, D) lnpool_bwd_k<T, D><<<B * ch, 256, 0, st>>>(g, (const T*)x, mean, rstd, (T*)dx, n_tok, ch, (T*)dxm, mseed, mp)
     if (dtype == HWGAT_F32) { SW(float) }
     else if (dtype == HWGAT_BF16) { SW(bf16_t) }
     else return HWGAT_EDTYPE;

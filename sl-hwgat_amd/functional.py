@@ -296,7 +296,9 @@ def temporal_merge(x):
 # ---------------------------------------------------------------- LN + pool
 class _LnPool(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta):
+    def forward(ctx, x, gamma, beta, xc=None, up=None):
+        # xc / up: carrier of the masked gradient for the block that produced x (block.fused_block)
+        ctx.up = up if (xc is not None and up is not None and up[1] > 0.0) else None
         B, d = x.shape[0], x.shape[-1]
         n_tok = x.numel() // (B * d)
         hat = torch.zeros(B, d, device=x.device, dtype=torch.float32)
@@ -315,14 +317,19 @@ class _LnPool(torch.autograd.Function):
         dfeat = dfeat.float()
         g = (dfeat * gamma / n_tok).contiguous()
         dx = torch.empty_like(x)
-        call("hwgat_lnpool_bwd", ptr(g), ptr(x), ptr(mean), ptr(rstd), ptr(dx), B, n_tok, d,
-             dtype_code(x), stream())
-        return dx, (dfeat * hat_mean).sum(0), dfeat.sum(0)
+        dxm = torch.empty_like(x) if ctx.up is not None else None
+        call("hwgat_lnpool_bwd_masked", ptr(g), ptr(x), ptr(mean), ptr(rstd), ptr(dx), B, n_tok, d,
+             dtype_code(x), ptr(dxm), (ctx.up[0] if ctx.up else 0) & 0xFFFFFFFF, float(ctx.up[1]) if ctx.up else 0.0, stream())
+        return dx, (dfeat * hat_mean).sum(0), dfeat.sum(0), dxm, None
 
 
-def ln_mean_pool(x, gamma, beta):
-    """final LayerNorm + mean over all tokens -> (B, d) fp32."""
-    return _LnPool.apply(x.contiguous(), gamma, beta)
+def ln_mean_pool(x, gamma, beta, carrier=None, up=None):
+    """final LayerNorm + mean over all tokens -> (B, d) fp32.  carrier / up: see block.fused_block (the last block's
+    fc2-dropout mask is applied to its incoming gradient here, once)."""
+    xcont = x.contiguous()
+    if carrier is not None and (xcont is not x or carrier.shape != x.shape):
+        carrier = None
+    return _LnPool.apply(xcont, gamma, beta, carrier, up)
 
 
 # ---------------------------------------------------------------- fp32 MFMA linears

@@ -179,7 +179,8 @@ class Model(nn.Module):
             seeds = self._seeds(k)
             out, st, oc = fused_block(h, thr, blk, self._mask_bits, n_heads, shifted, p, seeds, self._attn_kind,
                                       stats=have, want_stats=want, merge_out=merge, return_stats=True,
-                                      carrier=carrier, up=up, carry_out=want and not merge, return_carrier=True)
+                                      carrier=carrier, up=up, carry_out=(want or k == getattr(self, "_last_block", -1)) and not merge,
+                                      return_carrier=True)
             self._row_stats = (out, st) if st is not None else None
             self._carrier = (out, oc, (seeds[2], p)) if oc is not None else None
             return out
@@ -214,6 +215,7 @@ class Model(nn.Module):
         n_blocks = sum(len(st.blocks) for st in self.layers)
         self._row_stats = None
         self._carrier = None
+        self._last_block = n_blocks - 1
         self._plan, kk = {}, 0
         for i, stage in enumerate(self.layers):          # every block but the last feeds a LayerNorm; stage ends merge
             for j in range(len(stage.blocks)):
@@ -232,7 +234,9 @@ class Model(nn.Module):
             if i < self.num_layers - 1 and h.shape[-1] == self.embed_dim * 2 ** i:
                 h = HF.temporal_merge(h)                  # the fc2 epilogue could not store merged (bf16 / ragged M)
         self._row_stats = None
-        self._carrier = None
+        cr, self._carrier = self._carrier, None
+        if cr is not None and cr[0] is h:
+            return HF.ln_mean_pool(h, self.norm.weight, self.norm.bias, carrier=cr[1], up=cr[2])
         return HF.ln_mean_pool(h, self.norm.weight, self.norm.bias)
 
     def forward(self, x):

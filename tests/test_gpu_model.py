@@ -267,6 +267,44 @@ def test_dropout_mask_applied_once_by_the_consumer_equals_hashing_in_the_loaders
     assert rel_err(gx2, gx0.double()) < tol
     for n in gp0:
         assert rel_err(gp2[n], gp0[n].double()) < tol, n
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_whole_model_gradients_do_not_depend_on_where_the_dropout_masks_are_applied(dtype):
+    """train mode, drop 0.1, the whole HWGATE model (3 stages: carriers between blocks, the masked un-merge at the two
+    stage ends, the masked pooled-LayerNorm backward behind the last block) with HWGAT_MASK_ONCE = 0 / 1 / 2: the same
+    masks (seeds pinned), so the same loss and the same gradients up to summation order."""
+    HF = hw.functional
+    hp = hw.HWGATEParams({"src_len": 16, "num_class": 5}, 2, DEV, num_kps=32)
+    hp.drop_rate = 0.1
+    torch.manual_seed(3)
+    model = hw.Model(*hp.get_model_params()).to(DEV)
+    if dtype == "bf16":
+        model.activation_dtype = torch.bfloat16
+    model.train()
+    model.threshold_override = [0.3, 0.2, 0.25, 0.4, 0.15, 0.35, 0.1, 0.45]
+    x = torch.rand(4, 16, 32, 2, device=DEV)
+    y = torch.tensor([0, 1, 2, 3], device=DEV)
+    saved = HF.MASK_ONCE
+    res = []
+    try:
+        for mode in (0, 1, 2):
+            HF.MASK_ONCE = mode
+            model._drop_calls = 41                      # same dropout seeds in every run
+            for q in model.parameters():
+                q.grad = None
+            loss = torch.nn.functional.cross_entropy(model(x).float(), y)
+            loss.backward()
+            res.append((float(loss.detach()), {n: q.grad.clone().float().cpu() for n, q in model.named_parameters() if q.grad is not None}))
+    finally:
+        HF.MASK_ONCE = saved
+    tol = 5e-5 if dtype == "f32" else 3e-2
+    for mode in (1, 2):
+        assert abs(res[mode][0] - res[0][0]) < (1e-5 if dtype == "f32" else 2e-2)
+        for n, g0 in res[0][1].items():
+            if n.endswith("attn.qkv.bias"):
+                continue                                # the key third has an exactly-zero true gradient: pure rounding noise
+            assert rel_err(res[mode][1][n], g0.double()) < tol, (mode, n)
+
+
 def test_micro_batched_step_equals_full_batch_step():
     from importlib import import_module
     tr = import_module("sl-hwgat_amd.train")
