@@ -101,8 +101,9 @@ class _FusedBlock(torch.autograd.Function):
         ctx.save_for_backward(x, thr, n1w, n1b, wqkv, wp, n2w, n2b, w1, w2, m1, r1, qkv, o, y, m2, r2, h1, u)
         ctx.cfg = cfg
         ctx.merged = merged
-        ctx.send_up = xc is not None and up is not None and p > 0.0
-        carry = bool(carry_out) and not merged and p > 0.0 and HF.MASK_ONCE >= 2
+        wide = d >= HF.MASK_ONCE_MIN_D
+        ctx.send_up = xc is not None and up is not None and p > 0.0 and wide
+        carry = bool(carry_out) and not merged and p > 0.0 and HF.MASK_ONCE >= 2 and wide
         oc = x.new_zeros(1).expand(out.shape) if carry else x.new_empty(0)
         if carry:
             ctx.mark_non_differentiable(mo, ro)
@@ -120,7 +121,7 @@ class _FusedBlock(torch.autograd.Function):
         dout = dout.contiguous()
         if ctx.merged:                            # the gradient arrives in the merged layout: back to (B, F, K, d)
             nat = torch.empty_like(x)
-            if p > 0.0 and HF.MASK_ONCE >= 2:     # ... and once more multiplied by this block's fc2-dropout mask
+            if p > 0.0 and HF.MASK_ONCE >= 2 and d >= HF.MASK_ONCE_MIN_D:   # ... and once more multiplied by this block's fc2-dropout mask
                 doutm = torch.empty_like(x)
                 HF.call("hwgat_unmerge_masked", HF.ptr(dout), HF.ptr(nat), HF.ptr(doutm), B, F, K, d, HF.dtype_code(dout),
                         seeds[2] & 0xFFFFFFFF, float(p), HF.stream())
@@ -153,7 +154,7 @@ class _FusedBlock(torch.autograd.Function):
         dwq.run(lambda: HF.linear_tn(d_h1, y, dw1, db1, ln=(m2, r2, n2w, n2b)))
         d_z = HF.linear_nt(d_h1, HF.transpose(w1, dt), None, epi=HF.EPI_NONE)
         # ---- attention branch: y = x + drop1(o Wp^T + bp)
-        if p > 0.0 and HF.MASK_ONCE >= 1:
+        if p > 0.0 and HF.MASK_ONCE >= 1 and d >= HF.MASK_ONCE_MIN_D:
             d_y, d_ym = HF.ln_backward(d_z, y, m2, r2, n2w, dout, dn2w, dn2b, mask=(seeds[0], p))   # + shortcut; and dropmask1 * d_y
             dwq.run(lambda: HF.linear_tn(d_ym, o, dwp, dbp))
             d_o = HF.linear_nt(d_ym, HF.transpose(wp, dt), None, epi=HF.EPI_NONE, out=d_z)

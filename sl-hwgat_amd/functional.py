@@ -342,6 +342,9 @@ LN_FOLD = os.environ.get("HWGAT_LN_FOLD", "1") != "0"
 # LayerNorm backward that produces a gradient also writes its masked copy once (hwgat_ln_bwd_masked) for the block's own
 # projection dropout; 2 (default) = also across blocks, for the fc2 dropout of the block that produced this block's input.
 MASK_ONCE = int(os.environ.get("HWGAT_MASK_ONCE", "2"))
+# ... for blocks at least this wide: at d = 128 the extra E-sized write costs what the mask loaders cost there
+# (measured: WGATE, 8 blocks of d = 128, 1 468 -> 1 441 clips/s with masked copies everywhere)
+MASK_ONCE_MIN_D = int(os.environ.get("HWGAT_MASK_ONCE_MIN_D", "256"))
 EPI_BIAS, EPI_BIAS_DROP_RES, EPI_BIAS_GELU_DROP, EPI_GELU_BWD, EPI_NONE, EPI_BIAS_GELU_DROP_G, EPI_MUL_AUX = 0, 1, 2, 3, 4, 5, 6
 
 

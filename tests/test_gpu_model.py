@@ -242,7 +242,8 @@ def test_dropout_mask_applied_once_by_the_consumer_equals_hashing_in_the_loaders
     s0, s1 = [11, 22, 33], [44, 55, 66]
     g = None
     results = []
-    saved = HF.MASK_ONCE
+    saved, saved_d = HF.MASK_ONCE, HF.MASK_ONCE_MIN_D
+    HF.MASK_ONCE_MIN_D = 128                      # the default keeps d = 128 blocks on the loader path
     try:
         for mode in (0, 2):
             HF.MASK_ONCE = mode
@@ -260,7 +261,7 @@ def test_dropout_mask_applied_once_by_the_consumer_equals_hashing_in_the_loaders
                 for q in b.parameters():
                     q.grad = None
     finally:
-        HF.MASK_ONCE = saved
+        HF.MASK_ONCE, HF.MASK_ONCE_MIN_D = saved, saved_d
     tol = 2e-5 if dtype == "f32" else 1.5e-2
     (o0, gx0, gp0), (o2, gx2, gp2) = results
     assert rel_err(o2, o0.double()) < (1e-6 if dtype == "f32" else 1e-2)   # the forward is the same code (row statistics: atomics)
@@ -283,7 +284,8 @@ def test_whole_model_gradients_do_not_depend_on_where_the_dropout_masks_are_appl
     model.threshold_override = [0.3, 0.2, 0.25, 0.4, 0.15, 0.35, 0.1, 0.45]
     x = torch.rand(4, 16, 32, 2, device=DEV)
     y = torch.tensor([0, 1, 2, 3], device=DEV)
-    saved = HF.MASK_ONCE
+    saved, saved_d = HF.MASK_ONCE, HF.MASK_ONCE_MIN_D
+    HF.MASK_ONCE_MIN_D = 128
     res = []
     try:
         for mode in (0, 1, 2):
@@ -295,7 +297,7 @@ def test_whole_model_gradients_do_not_depend_on_where_the_dropout_masks_are_appl
             loss.backward()
             res.append((float(loss.detach()), {n: q.grad.clone().float().cpu() for n, q in model.named_parameters() if q.grad is not None}))
     finally:
-        HF.MASK_ONCE = saved
+        HF.MASK_ONCE, HF.MASK_ONCE_MIN_D = saved, saved_d
     tol = 5e-5 if dtype == "f32" else 3e-2
     for mode in (1, 2):
         assert abs(res[mode][0] - res[0][0]) < (1e-5 if dtype == "f32" else 2e-2)
