@@ -148,6 +148,64 @@ def test_ln_bwd_residual_argument():
     assert torch.equal(dg[0], dg[2]) or torch.allclose(dg[0], dg[2], rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("d", [128, 256, 512])
+def test_masked_gradient_copies_equal_gradient_times_dropout_mask(d, dtype):
+    """hwgat_ln_bwd_masked, hwgat_unmerge_masked, hwgat_lnpool_bwd_masked: the second output is the first one times the
+    very mask hwgat_dropout_mask_f32 generates for (seed, element index); the first output is what the plain entry
+    point writes."""
+    g = torch.Generator().manual_seed(d)
+    L = hw._lib
+    dc = 0 if dtype == torch.float32 else 1
+    seed, p = 4711, 0.1
+    tol = 1e-6 if dtype == torch.float32 else 8e-3
+
+    def masked_ok(plain, masked, shape):
+        m = HF.dropout_mask(shape, seed, p, DEV).view_as(plain)
+        return rel_err(masked.float().cpu(), (plain.float() * m).cpu().double()) < tol
+
+    # --- LayerNorm backward
+    n = 300
+    x, dy, res = (torch.randn(n, d, generator=g).to(DEV).to(dtype) for _ in range(3))
+    w = torch.randn(d, generator=g).to(DEV)
+    mean, rstd = HF.ln_stats(x, w, w)
+    dx0, dx1, dxm = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+    dg = torch.zeros(4, d, device=DEV)
+    L.call("hwgat_ln_bwd", L.ptr(dy), L.ptr(x), L.ptr(mean), L.ptr(rstd), L.ptr(w), L.ptr(res), L.ptr(dx0),
+           L.ptr(dg[0]), L.ptr(dg[1]), n, d, dc, L.stream())
+    L.call("hwgat_ln_bwd_masked", L.ptr(dy), L.ptr(x), L.ptr(mean), L.ptr(rstd), L.ptr(w), L.ptr(res), L.ptr(dx1),
+           L.ptr(dg[2]), L.ptr(dg[3]), n, d, dc, L.ptr(dxm), seed, p, L.stream())
+    assert torch.equal(dx0, dx1) and torch.allclose(dg[0], dg[2], rtol=1e-5, atol=1e-5)
+    if dtype == torch.float32:
+        assert masked_ok(dx1, dxm, (n, d))
+    else:                                           # the masked copy is rounded from the fp32 value, not from the rounded dx
+        m = HF.dropout_mask((n, d), seed, p, DEV)
+        assert rel_err(dxm.float().cpu(), (dx1.float() * m).cpu().double()) < tol
+    # --- un-merge
+    B, F, K = 2, 8, 32
+    merged = torch.randn(B, F // 2, K, 2 * d, generator=g).to(DEV).to(dtype)
+    nat0, nat1, natm = (torch.empty(B, F, K, d, device=DEV, dtype=dtype) for _ in range(3))
+    L.call("hwgat_merge", L.ptr(merged), L.ptr(nat0), B, F, K, d, 1, dc, L.stream())
+    L.call("hwgat_unmerge_masked", L.ptr(merged), L.ptr(nat1), L.ptr(natm), B, F, K, d, dc, seed, p, L.stream())
+    assert torch.equal(nat0, nat1)
+    assert masked_ok(nat1, natm, (B, F, K, d))
+    # --- pooled LayerNorm backward
+    n_tok = 96
+    x = torch.randn(B, n_tok, d, generator=g).to(DEV).to(dtype)
+    gvec = torch.randn(B, d, generator=g).to(DEV)
+    mean, rstd = HF.ln_stats(x.view(B * n_tok, d), w, w)
+    p0, p1, pm = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+    L.call("hwgat_lnpool_bwd", L.ptr(gvec), L.ptr(x), L.ptr(mean), L.ptr(rstd), L.ptr(p0), B, n_tok, d, dc, L.stream())
+    L.call("hwgat_lnpool_bwd_masked", L.ptr(gvec), L.ptr(x), L.ptr(mean), L.ptr(rstd), L.ptr(p1), B, n_tok, d, dc, L.ptr(pm),
+           seed, p, L.stream())
+    assert torch.equal(p0, p1)
+    if dtype == torch.float32:
+        assert masked_ok(p1, pm, (B, n_tok, d))
+    else:
+        m = HF.dropout_mask((B, n_tok, d), seed, p, DEV)
+        assert rel_err(pm.float().cpu(), (p1.float() * m).cpu().double()) < tol
+
+
 @pytest.mark.parametrize("C,d0,J,nW", [(2, 128, 29, 4), (3, 256, 133, 7), (2, 128, 32, 2)])
 def test_embed(C, d0, J, nW):
     g = torch.Generator().manual_seed(C * 7 + nW)
