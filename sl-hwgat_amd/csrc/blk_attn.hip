@@ -86,13 +86,14 @@ __device__ __forceinline__ uint32_t masked_softmax64(float (&s)[2][16], float (&
 }
 
 template <typename T, int HD> struct BlkCfg {
-    static constexpr int LDW = HD + 4;
+    using E = typename tile_of<T>::E;          // LDS tile element: fp32 tiles + fp32 MFMAs, or raw bf16 tiles + bf16 MFMAs (attn_common.h)
+    static constexpr int LDW = HD + tile_of<T>::PAD;
     static constexpr int NT = HD / 32;
     static constexpr int EPV = io<T>::EPV;
     static constexpr int CPR = HD / EPV;       // 16-byte chunks per row
     static constexpr int RPI = 64 / CPR;       // rows per wave-wide load
     static constexpr int NLD = 32 / RPI;       // wave-wide loads per 32-row tile
-    static constexpr int TILE = 32 * LDW;      // floats per LDS tile
+    static constexpr int TILE = 32 * LDW;      // elements per LDS tile
 };
 
 // =============================================================== forward
@@ -103,10 +104,12 @@ __global__ __launch_bounds__(128, 2) void blk_attn_fwd_k(const T* __restrict__ q
                                                       int n_units) {
     using C = BlkCfg<T, HD>;
     constexpr int LDW = C::LDW, NT = C::NT, NLD = C::NLD, RPI = C::RPI, TILE = C::TILE;
-    __shared__ __attribute__((aligned(16))) float smem[6 * TILE];      // Q0 Q1 K0 K1 V0 V1
-    float* Qs = smem;
-    float* Ks = smem + 2 * TILE;
-    float* Vs = smem + 4 * TILE;
+    using E = typename C::E;
+    constexpr bool QS = tile_of<T>::QSCALED;
+    __shared__ __attribute__((aligned(16))) E smem[6 * TILE];          // Q0 Q1 K0 K1 V0 V1
+    E* Qs = smem;
+    E* Ks = smem + 2 * TILE;
+    E* Vs = smem + 4 * TILE;
 
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, lq = lane & 31, hh = lane >> 5;
     const int crow_l = lane / C::CPR, ccol = (lane % C::CPR) * C::EPV;
@@ -140,9 +143,9 @@ __global__ __launch_bounds__(128, 2) void blk_attn_fwd_k(const T* __restrict__ q
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int off = (w * 32 + i * RPI + crow_l) * LDW + ccol;
-            chunk<T>::to_lds(Qs + off, qr[i], qk_scale<HD>());
-            chunk<T>::to_lds(Ks + off, kr[i], 1.0f);
-            chunk<T>::to_lds(Vs + off, vr[i], 1.0f);
+            raw_to_lds(Qs + off, qr[i], qk_scale<HD>(), T());
+            raw_to_lds(Ks + off, kr[i], 1.0f, T());
+            raw_to_lds(Vs + off, vr[i], 1.0f, T());
         }
         const uint32_t mb0 = maskbits[(cur.mrow + w * 32 + lq) * 2];
         const uint32_t mb1 = maskbits[(cur.mrow + w * 32 + lq) * 2 + 1];
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(128, 2) void blk_attn_fwd_k(const T* __restrict__ q
         for (int kt = 0; kt < 2; ++kt) {
             f32x16 st = tile_xyT<HD, LDW>(Ks + kt * TILE, Qs + w * TILE, lq, hh);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[kt][r] = st[r];
+            for (int r = 0; r < 16; ++r) s[kt][r] = QS ? st[r] : st[r] * qk_scale<HD>();
         }
         masked_softmax64(s, p, mb0, mb1, hh, g.KJ);
 
@@ -190,12 +193,14 @@ __global__ __launch_bounds__(128) void blk_attn_bwd_k(const T* __restrict__ qkv,
                                                       int n_units) {
     using C = BlkCfg<T, HD>;
     constexpr int LDW = C::LDW, NT = C::NT, NLD = C::NLD, RPI = C::RPI, TILE = C::TILE;
+    using E = typename C::E;
+    constexpr bool QS = tile_of<T>::QSCALED, B16 = sizeof(T) == 2;
     constexpr int TW = 66;                                   // scratch row stride: [64 q slots][64 key slots]
-    __shared__ __attribute__((aligned(16))) float smem[6 * TILE + 64 * TW];   // Q0 Q1 K0 K1 G0 G1 | scratch
-    float* Qs = smem;
-    float* Ks = smem + 2 * TILE;
-    float* Gs = smem + 4 * TILE;
-    float* Sc = smem + 6 * TILE;
+    __shared__ __attribute__((aligned(16))) E smem[6 * TILE + 64 * TW];   // Q0 Q1 K0 K1 G0 G1 | scratch
+    E* Qs = smem;
+    E* Ks = smem + 2 * TILE;
+    E* Gs = smem + 4 * TILE;
+    E* Sc = smem + 6 * TILE;
 
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, lq = lane & 31, hh = lane >> 5;
     const int crow_l = lane / C::CPR, ccol = (lane % C::CPR) * C::EPV;
@@ -225,8 +230,8 @@ __global__ __launch_bounds__(128) void blk_attn_bwd_k(const T* __restrict__ qkv,
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int off = (w * 32 + i * RPI + crow_l) * LDW + ccol;
-            chunk<T>::to_lds(Qs + off, qr[i], qk_scale<HD>());
-            chunk<T>::to_lds(Ks + off, kr[i], 1.0f);
+            raw_to_lds(Qs + off, qr[i], qk_scale<HD>(), T());
+            raw_to_lds(Ks + off, kr[i], 1.0f, T());
         }
         // dO tile w (to LDS behind the S product) and V rows in the row-per-lane operand layout
 #pragma unroll
@@ -237,17 +242,26 @@ __global__ __launch_bounds__(128) void blk_attn_bwd_k(const T* __restrict__ qkv,
                                                             + cur.head * HD + ccol);
             gr[i] = ok ? a : zero4;
         }
-        float vx[2][HD / 8][4];                                  // V[key = kt*32 + lq][8m + 4hh + 0..3]
+        float vx[B16 ? 1 : 2][B16 ? 1 : HD / 8][4];              // fp32: V[key = kt*32 + lq][8m + 4hh + 0..3]
+        u32x4 vxb[B16 ? 2 : 1][B16 ? HD / 16 : 1];               // bf16: V[key][16m + 8hh + 0..7], raw = one MFMA operand
         {
             const bool ok = lq < g.KJ;
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) {
-                const T* vp = qkv + (cur.base[kt] + (ok ? lq : g.KJ - 1)) * row3d + 2 * g.d + cur.head * HD + 4 * hh;
+                const T* vp = qkv + (cur.base[kt] + (ok ? lq : g.KJ - 1)) * row3d + 2 * g.d + cur.head * HD;
+                if constexpr (B16) {
 #pragma unroll
-                for (int m = 0; m < HD / 8; ++m) {
-                    load_nt<T, 4>(vp + 8 * m, vx[kt][m]);
+                    for (int m = 0; m < HD / 16; ++m) {
+                        const u32x4 t = *reinterpret_cast<const u32x4*>(vp + 16 * m + 8 * hh);
+                        vxb[kt][m] = ok ? t : zero4;
+                    }
+                } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) vx[kt][m][e] = ok ? vx[kt][m][e] : 0.f;
+                    for (int m = 0; m < HD / 8; ++m) {
+                        load_nt<T, 4>(vp + 4 * hh + 8 * m, vx[kt][m]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) vx[kt][m][e] = ok ? vx[kt][m][e] : 0.f;
+                    }
                 }
             }
         }
@@ -263,29 +277,37 @@ __global__ __launch_bounds__(128) void blk_attn_bwd_k(const T* __restrict__ qkv,
         for (int kt = 0; kt < 2; ++kt) {
             f32x16 st = tile_xyT<HD, LDW>(Ks + kt * TILE, Qs + w * TILE, lq, hh);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[kt][r] = st[r];
+            for (int r = 0; r < 16; ++r) s[kt][r] = QS ? st[r] : st[r] * qk_scale<HD>();
         }
         const uint32_t nz = masked_softmax64(s, p, mb0, mb1, hh, g.KJ);
 #pragma unroll
         for (int i = 0; i < NLD; ++i)
-            chunk<T>::to_lds(Gs + (w * 32 + i * RPI + crow_l) * LDW + ccol, gr[i], 1.0f);
+            raw_to_lds(Gs + (w * 32 + i * RPI + crow_l) * LDW + ccol, gr[i], 1.0f, T());
         lds_fence();                                             // own dO tile visible to this wave
         // dP^T[key][q] = V dO_w^T ; dS = P (dP - delta) where the logit was kept
         {
             float delta = 0.f;
-            const float* yr = Gs + (w * 32 + lq) * LDW + 4 * hh;
+            const E* yr = Gs + (w * 32 + lq) * LDW + (B16 ? 8 : 4) * hh;
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) {
                 f32x16 dp;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) dp[i] = 0.f;
+                if constexpr (B16) {
 #pragma unroll
-                for (int m = 0; m < HD / 8; ++m) {
-                    const f32x4 yf = *reinterpret_cast<const f32x4*>(yr + 8 * m);
-                    dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vx[kt][m][0], yf.x, dp, 0, 0, 0);
-                    dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vx[kt][m][1], yf.y, dp, 0, 0, 0);
-                    dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vx[kt][m][2], yf.z, dp, 0, 0, 0);
-                    dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vx[kt][m][3], yf.w, dp, 0, 0, 0);
+                    for (int m = 0; m < HD / 16; ++m) {
+                        const bf16x8 yf = *reinterpret_cast<const bf16x8*>(yr + 16 * m);
+                        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vxb[kt][m]), yf, dp, 0, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int m = 0; m < HD / 8; ++m) {
+                        const f32x4 yf = *reinterpret_cast<const f32x4*>(yr + 8 * m);
+                        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vx[kt][m][0], yf.x, dp, 0, 0, 0);
+                        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vx[kt][m][1], yf.y, dp, 0, 0, 0);
+                        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vx[kt][m][2], yf.z, dp, 0, 0, 0);
+                        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vx[kt][m][3], yf.w, dp, 0, 0, 0);
+                    }
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { ds[kt][r] = dp[r]; delta += p[kt][r] * dp[r]; }
@@ -319,12 +341,7 @@ __global__ __launch_bounds__(128) void blk_attn_bwd_k(const T* __restrict__ qkv,
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    float* pp = Sc + (w * 32 + lq) * TW + kt * 32 + 8 * gq + 4 * hh;
-                    f32x2 a0 = {x[kt][4 * gq], x[kt][4 * gq + 1]}, a1 = {x[kt][4 * gq + 2], x[kt][4 * gq + 3]};
-                    reinterpret_cast<f32x2*>(pp)[0] = a0;
-                    reinterpret_cast<f32x2*>(pp)[1] = a1;
-                }
+                for (int gq = 0; gq < 4; ++gq) put4(Sc + (w * 32 + lq) * TW + kt * 32 + 8 * gq + 4 * hh, x[kt] + 4 * gq);
         };
         put(ds);
         __syncthreads();                                         // (2) dS of both query tiles + both dO tiles visible
@@ -335,7 +352,7 @@ __global__ __launch_bounds__(128) void blk_attn_bwd_k(const T* __restrict__ qkv,
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) a[r] = Sc[(qt * 32 + crow(r, hh)) * TW + w * 32 + lq];
+            for (int r = 0; r < 16; ++r) a[r] = (float)Sc[(qt * 32 + crow(r, hh)) * TW + w * 32 + lq];
             if (qt == 0) tile_ay<HD, LDW, true>(a, Qs, lq, hh, acc);
             else tile_ay<HD, LDW, false>(a, Qs + TILE, lq, hh, acc);
         }
@@ -343,7 +360,7 @@ __global__ __launch_bounds__(128) void blk_attn_bwd_k(const T* __restrict__ qkv,
         for (int r = 0; r < 16; ++r) {
             float ov[NT];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) ov[nt] = acc[nt][r];
+            for (int nt = 0; nt < NT; ++nt) ov[nt] = QS ? acc[nt][r] : acc[nt][r] * qk_scale<HD>();
             if (crow(r, hh) < g.KJ) store_nt<T, NT>(gbase + (base_w + crow(r, hh)) * row3d + g.d, ov);
         }
         __syncthreads();                                         // (3) dS scratch consumed
@@ -353,7 +370,7 @@ __global__ __launch_bounds__(128) void blk_attn_bwd_k(const T* __restrict__ qkv,
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) a[r] = Sc[(qt * 32 + crow(r, hh)) * TW + w * 32 + lq];
+            for (int r = 0; r < 16; ++r) a[r] = (float)Sc[(qt * 32 + crow(r, hh)) * TW + w * 32 + lq];
             if (qt == 0) tile_ay<HD, LDW, true>(a, Gs, lq, hh, acc);
             else tile_ay<HD, LDW, false>(a, Gs + TILE, lq, hh, acc);
         }
@@ -376,7 +393,7 @@ constexpr int LDS_PER_CU = 160 * 1024;
 
 template <typename T, int HD>
 int launch_bfwd(const void* qkv, void* o, const uint32_t* mb, BlkGeom g, int n_units, hipStream_t st) {
-    constexpr int per_cu = LDS_PER_CU / (6 * BlkCfg<T, HD>::TILE * 4);
+    constexpr int per_cu = LDS_PER_CU / (6 * BlkCfg<T, HD>::TILE * (int)sizeof(typename BlkCfg<T, HD>::E));
     const int blocks = min(n_units, 256 * (per_cu > 8 ? 8 : per_cu));
     blk_attn_fwd_k<T, HD><<<blocks, 128, 0, st>>>((const T*)qkv, (T*)o, mb, g, n_units);
     HWGAT_LAUNCH_CHECK();
@@ -384,7 +401,7 @@ int launch_bfwd(const void* qkv, void* o, const uint32_t* mb, BlkGeom g, int n_u
 template <typename T, int HD>
 int launch_bbwd(const void* qkv, const void* dO, void* dqkv, const uint32_t* mb, BlkGeom g, int n_units,
                 hipStream_t st) {
-    constexpr int per_cu = LDS_PER_CU / ((6 * BlkCfg<T, HD>::TILE + 64 * 66) * 4);
+    constexpr int per_cu = LDS_PER_CU / ((6 * BlkCfg<T, HD>::TILE + 64 * 66) * (int)sizeof(typename BlkCfg<T, HD>::E));
     const int blocks = min(n_units, 256 * (per_cu > 4 ? 4 : per_cu));
     blk_attn_bwd_k<T, HD><<<blocks, 128, 0, st>>>((const T*)qkv, (const T*)dO, (T*)dqkv, mb, g, n_units);
     HWGAT_LAUNCH_CHECK();
