@@ -118,6 +118,8 @@ class _FusedBlock(torch.autograd.Function):
         up = ctx.cfg[8]
         B, F, K, d = x.shape
         dt = x.dtype
+        if not (dout.is_contiguous() and HF.carry_valid(dout, doutm)):
+            doutm = None                          # no carrier, or dout is not (only) the dx the masked copy was made from
         dout = dout.contiguous()
         if ctx.merged:                            # the gradient arrives in the merged layout: back to (B, F, K, d)
             nat = torch.empty_like(x)
@@ -174,6 +176,7 @@ class _FusedBlock(torch.autograd.Function):
             dx, dxm = HF.ln_backward(d_xn, x, m1, r1, n1w, d_y, dn1w, dn1b, mask=up)
         else:
             dx = HF.ln_backward(d_xn, x, m1, r1, n1w, d_y, dn1w, dn1b)
+        HF.carry_register(dx, dxm)
         dwq.join()        # every temporary above stays referenced until here, so the allocator cannot recycle it early
         return (dx, dxm, None, None, None, dn1w, dn1b, dwqkv, dbqkv, dwp, dbp, dn2w, dn2b, dw1, db1, dw2, db2, None)
 

@@ -320,6 +320,7 @@ class _LnPool(torch.autograd.Function):
         dxm = torch.empty_like(x) if ctx.up is not None else None
         call("hwgat_lnpool_bwd_masked", ptr(g), ptr(x), ptr(mean), ptr(rstd), ptr(dx), B, n_tok, d,
              dtype_code(x), ptr(dxm), (ctx.up[0] if ctx.up else 0) & 0xFFFFFFFF, float(ctx.up[1]) if ctx.up else 0.0, stream())
+        carry_register(dx, dxm)
         return dx, (dfeat * hat_mean).sum(0), dfeat.sum(0), dxm, None
 
 
@@ -345,6 +346,25 @@ MASK_ONCE = int(os.environ.get("HWGAT_MASK_ONCE", "2"))
 # ... for blocks at least this wide: at d = 128 the extra E-sized write costs what the mask loaders cost there
 # (measured: WGATE, 8 blocks of d = 128, 1 468 -> 1 441 clips/s with masked copies everywhere)
 MASK_ONCE_MIN_D = int(os.environ.get("HWGAT_MASK_ONCE_MIN_D", "256"))
+# A masked copy handed to the producing block through a carrier is only valid if the gradient that block receives IS the
+# dx it was made from.  If the tensor has another consumer (an auxiliary loss on a block output, say) autograd adds that
+# gradient to dx -- in a new tensor, or in place -- and the copy would miss it.  The consumer therefore registers
+# (address, version counter) of its dx under the address of the masked copy; the producer uses the copy only if the
+# gradient it got still has exactly that address and version, and otherwise masks the real gradient in its loaders.
+_CARRY = {}
+
+
+def carry_register(dx, dxm):
+    if dxm is not None:
+        _CARRY[dxm.data_ptr()] = (dx.data_ptr(), dx._version, tuple(dx.shape))
+
+
+def carry_valid(dout, doutm):
+    """True iff `doutm` is the registered masked copy of exactly this `dout`"""
+    if doutm is None:
+        return False
+    rec = _CARRY.pop(doutm.data_ptr(), None)
+    return rec is not None and rec == (dout.data_ptr(), dout._version, tuple(dout.shape))
 EPI_BIAS, EPI_BIAS_DROP_RES, EPI_BIAS_GELU_DROP, EPI_GELU_BWD, EPI_NONE, EPI_BIAS_GELU_DROP_G, EPI_MUL_AUX = 0, 1, 2, 3, 4, 5, 6
 
 

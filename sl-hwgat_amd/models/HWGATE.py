@@ -216,6 +216,7 @@ class Model(nn.Module):
         self._row_stats = None
         self._carrier = None
         self._last_block = n_blocks - 1
+        HF._CARRY.clear()                 # registrations of a backward pass that never reached their producer
         self._plan, kk = {}, 0
         for i, stage in enumerate(self.layers):          # every block but the last feeds a LayerNorm; stage ends merge
             for j in range(len(stage.blocks)):

@@ -268,6 +268,50 @@ def test_dropout_mask_applied_once_by_the_consumer_equals_hashing_in_the_loaders
     assert rel_err(gx2, gx0.double()) < tol
     for n in gp0:
         assert rel_err(gp2[n], gp0[n].double()) < tol, n
+def test_masked_copy_is_dropped_when_the_block_output_has_another_consumer():
+    """the carrier's masked gradient is only valid if nothing else feeds the producing block's output gradient: with an
+    extra loss on the intermediate tensor autograd adds to dx, the registration no longer matches and the producer must
+    fall back to masking the real gradient -- same gradients as the loader path."""
+    torch.manual_seed(9)
+    B, F, K, d, nH, p = 2, 8, 32, 128, 2, 0.1
+    hp = hw.HWGATEParams({"src_len": 16, "num_class": 3}, 2, DEV, num_kps=K)
+    model = hw.Model(*hp.get_model_params()).to(DEV)
+    blks = [model.layers[0].blocks[0], model.layers[0].blocks[1]]
+    for b in blks:
+        for prm in b.parameters():
+            prm.data.normal_(0, 0.1)
+    from importlib import import_module
+    fb = import_module("sl-hwgat_amd.block")
+    HF = hw.functional
+    x0 = torch.randn(B, F, K, d, device=DEV)
+    wext = torch.randn(B, F, K, d, device=DEV)
+    thr = torch.tensor([0.2], device=DEV)
+    s0, s1 = [11, 22, 33], [44, 55, 66]
+    g = None
+    res = []
+    saved, saved_d = HF.MASK_ONCE, HF.MASK_ONCE_MIN_D
+    HF.MASK_ONCE_MIN_D = 128
+    try:
+        for mode in (0, 2):
+            HF.MASK_ONCE = mode
+            x = x0.clone().requires_grad_(True)
+            h, st, oc = fb.fused_block(x, thr, blks[0], model._mask_bits, nH, False, p, s0, want_stats=True,
+                                       return_stats=True, carry_out=True)
+            out = fb.fused_block(h, thr, blks[1], model._mask_bits, nH, True, p, s1, stats=st, carrier=oc, up=(s0[2], p))
+            if g is None:
+                g = torch.randn_like(out)
+            ((out * g).sum() + (h * wext).sum()).backward()             # h has a second consumer
+            res.append((x.grad.cpu(), {f"{i}.{n}": q.grad.clone().cpu() for i, b in enumerate(blks) for n, q in b.named_parameters()}))
+            for b in blks:
+                for q in b.parameters():
+                    q.grad = None
+    finally:
+        HF.MASK_ONCE, HF.MASK_ONCE_MIN_D = saved, saved_d
+    assert rel_err(res[1][0], res[0][0].double()) < 2e-5
+    for n in res[0][1]:
+        assert rel_err(res[1][1][n], res[0][1][n].double()) < 2e-5, n
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_whole_model_gradients_do_not_depend_on_where_the_dropout_masks_are_applied(dtype):
     """train mode, drop 0.1, the whole HWGATE model (3 stages: carriers between blocks, the masked un-merge at the two
