@@ -173,17 +173,42 @@ def cpu_baseline(hgate=False, budget_s=45.0):
             "cells": cells, "seconds": round(time.perf_counter() - t_start, 1)}
 
 
+def visible_gpu_count():
+    """GPUs this node exposes, WITHOUT loading the HIP / HSA runtime in this process (the parent of the rank processes
+    must stay GPU-free): the *_VISIBLE_DEVICES lists if set, else the KFD topology (nodes with SIMDs are GPUs).
+    None = cannot tell (no KFD sysfs): the ranks find out themselves on torch.cuda.set_device()."""
+    import glob
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([t for t in v.split(",") if t.strip()])
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return None
+    n = 0
+    for path in nodes:
+        try:
+            with open(path) as fh:
+                props = dict(ln.split(None, 1) for ln in fh.read().splitlines() if " " in ln)
+            n += int(props.get("simd_count", "0")) > 0
+        except (OSError, ValueError):
+            return None
+    return n
+
+
 def spawn_ranks(n, argv):
     """Parent side of a plain `python bench.py --gpus N` (N > 1): one fresh process per GPU, started BEFORE this
-    process has touched the GPU (it never does: it only counts devices), each with RANK / LOCAL_RANK /
+    process has touched the GPU (it never does: devices are counted from the environment / KFD sysfs, never through
+    torch.cuda or HIP), each with RANK / LOCAL_RANK /
     WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT in its environment -- the same contract
     torch.distributed.run provides.  Rank 0's stdout (exactly one JSON line) is relayed to ours; everything
     else the ranks print goes to stderr.  Any rank failing ends the others and makes this process exit non-zero."""
     import socket
     import subprocess
     dry = os.environ.get("HWGAT_BENCH_DRYRUN") == "1"
-    if not dry and torch.cuda.device_count() < n:          # device_count() does not initialise HIP
-        sys.exit(f"bench.py --gpus {n}: only {torch.cuda.device_count()} GPU(s) visible on this node")
+    have = None if dry else visible_gpu_count()
+    if have is not None and have < n:
+        sys.exit(f"bench.py --gpus {n}: only {have} GPU(s) visible on this node")
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]

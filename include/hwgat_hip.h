@@ -35,7 +35,13 @@ extern "C" {
 #define HWGAT_ESHAPE (-2)   /* unsupported shape (head_dim, width, ...)    */
 #define HWGAT_EDTYPE (-3)   /* unknown dtype code                          */
 
-/* library / ABI version: major*1000 + minor */
+/* library / ABI version: major*1000 + minor.  The major number changes whenever an entry point is removed or its
+ * argument list / code tables (pro, epi, dtype) change meaning; a binding must compare hwgat_abi_version() with the
+ * HWGAT_ABI_VERSION of the header it was written against and refuse a mismatch (sl-hwgat_amd/_lib.py does).
+ *   1000  round 1 (incl. hwgat_split3_bf16, hwgat_linear_nt_f32x9 -- removed in 2000)
+ *   2000  round 2: *_ex linears, ln_fold / ln_finalize, epilogues 5 / 6, masked-gradient producers
+ *   3000  round 3: see INTEGRATION.md section 3 */
+#define HWGAT_ABI_VERSION 3000
 int hwgat_abi_version(void);
 
 /* ---- debug: dump the lane->element maps of v_mfma_f32_32x32x2_f32 so the

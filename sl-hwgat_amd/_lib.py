@@ -61,6 +61,12 @@ def declared_symbols():
     return sorted(set(re.findall(r"\bint\s+(hwgat_\w+)\s*\(", src)))
 
 
+def header_abi_version():
+    """HWGAT_ABI_VERSION of include/hwgat_hip.h, the header these bindings were written against"""
+    with open(HEADER) as fh:
+        return int(re.search(r"#define\s+HWGAT_ABI_VERSION\s+(\d+)", fh.read()).group(1))
+
+
 def _check_stamp():
     """refuse a library that was built from other sources than the ones in the tree (a stale .so would otherwise be
     tested and benchmarked silently): build.py writes the digest of csrc/ + the header + the flags next to the .so"""
@@ -90,6 +96,9 @@ def lib():
             fn = getattr(handle, name)
             fn.argtypes = args
             fn.restype = _I
+        have, want = handle.hwgat_abi_version(), header_abi_version()
+        if have != want:
+            raise RuntimeError(f"{LIB_PATH} reports ABI {have}, include/hwgat_hip.h declares {want}: rebuild the library")
         _lib = handle
     return _lib
 

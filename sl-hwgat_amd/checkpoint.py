@@ -21,7 +21,10 @@ _LISTS = ("train_loss_list", "val_loss_list", "train_acc_list", "val_acc_list")
 
 def get_optimizer(model, lr: float = 5e-4, optimizer_type: str = "adamw", fused: Optional[bool] = None):
     """utils.py:71-82 (configs.py:84: lr 5e-4, 'adamw').  `fused=True` selects torch's single-launch AdamW on a GPU."""
-    params = [p for p in model.parameters() if p.requires_grad]     # frozen B gets no update in the reference either
+    # ALL parameters, as the reference passes them (utils.py:76: model.parameters()): the frozen Fourier matrix `B`
+    # is an nn.Parameter and therefore entry 0 of the param group, so optimizer_state_dict files interchange with the
+    # reference's AdamW (param-group sizes must match).  AdamW skips parameters whose grad is None: B gets no update.
+    params = list(model.parameters())
     kinds = {"adamw": torch.optim.AdamW, "adam": torch.optim.Adam, "nadam": torch.optim.NAdam, "sgd": torch.optim.SGD}
     if optimizer_type not in kinds:
         raise ValueError(f"optimizer_type {optimizer_type!r}: one of {sorted(kinds)}")

@@ -157,4 +157,4 @@ extern "C" int hwgat_unmerge_masked(const void* in, void* out, void* out_masked,
     HWGAT_LAUNCH_CHECK();
 }
 
-extern "C" int hwgat_abi_version(void) { return 1000; }
+extern "C" int hwgat_abi_version(void) { return HWGAT_ABI_VERSION; }

@@ -37,6 +37,8 @@ class GradReducer:
         if cur:
             self._close(cur)
         self._handles = []
+        self._in_hook = False
+        self.trace = None          # tests: a list receives ("launch", bucket index, "hook" | "finish") per collective issued
         self._use_avg = dist.is_initialized() and dist.get_backend(group) == "nccl"
         for b in self.buckets:
             for p in b["params"]:
@@ -49,16 +51,22 @@ class GradReducer:
         for p in plist:
             p.grad = flat[off:off + p.numel()].view_as(p)    # .grad is a view into the bucket
             off += p.numel()
-        self.buckets.append({"flat": flat, "params": plist, "pending": len(plist)})
+        self.buckets.append({"flat": flat, "params": plist, "pending": len(plist), "index": len(self.buckets)})
 
     def _make_hook(self, bucket):
         def hook(_p):
             bucket["pending"] -= 1
             if bucket["pending"] == 0:
-                self._launch(bucket)
+                self._in_hook = True          # we are inside autograd's backward: the rest of it overlaps the collective
+                try:
+                    self._launch(bucket)
+                finally:
+                    self._in_hook = False
         return hook
 
     def _launch(self, bucket):
+        if self.trace is not None:
+            self.trace.append(("launch", bucket["index"], "hook" if self._in_hook else "finish"))
         if self.world > 1 or (self.always_reduce and dist.is_initialized()):
             if self._use_avg:
                 h = dist.all_reduce(bucket["flat"], op=dist.ReduceOp.AVG, group=self.group, async_op=True)

@@ -72,8 +72,41 @@ def test_checkpoint_file_written_here_loads_into_the_reference_class(tmp_path):
     # the reference's optimizer / scheduler accept the saved states (utils.py:228-229)
     opt_r = torch.optim.AdamW(ref.parameters(), lr=5e-4)
     sch_r = torch.optim.lr_scheduler.CosineAnnealingLR(opt_r, T_max=20, last_epoch=-1)
+    opt_r.load_state_dict(raw["optimizer_state_dict"])                          # same param-group size (B included)
     sch_r.load_state_dict(raw["scheduler"])
     assert sch_r.last_epoch == sch.last_epoch
+    assert len(opt_r.param_groups[0]["params"]) == len(opt.param_groups[0]["params"]) == len(list(ref.parameters()))
+
+
+def test_resume_from_a_file_whose_optimizer_state_the_reference_wrote(tmp_path):
+    """utils.py:76 builds AdamW(model.parameters()) -- frozen `B` included -- and utils.py:228 loads that state back:
+    a file written from the REFERENCE model + optimizer after two steps must resume here, moments per parameter name."""
+    ref, mine = _pair()
+    opt_r = torch.optim.AdamW(ref.parameters(), lr=5e-4)
+    sch_r = torch.optim.lr_scheduler.CosineAnnealingLR(opt_r, T_max=20, last_epoch=-1)
+    g = torch.Generator().manual_seed(5)
+    for _ in range(2):
+        for p in ref.parameters():
+            p.grad = torch.randn(p.shape, generator=g) * 1e-3 if p.requires_grad else None
+        opt_r.step()
+        sch_r.step()
+    path = str(tmp_path / "ref_written.pt")
+    torch.save({"model_state_dict": ref.state_dict(), "optimizer_state_dict": opt_r.state_dict(), "train_loss_list": [1.0],
+                "val_loss_list": [1.1], "train_acc_list": [0.1], "val_acc_list": [0.2], "epoch": 1,
+                "learning_rate": sch_r.get_last_lr()[0], "scheduler": sch_r.state_dict()}, path)
+    opt = ck.get_optimizer(mine)
+    sch = ck.get_scheduler(opt)
+    mine, opt, sch, lists, start = ck.load_checkpoint(path, mine, opt, sch)
+    assert start == 2 and sch.last_epoch == 2
+    names_r = [n for n, _ in ref.named_parameters()]
+    names_m = [n for n, _ in mine.named_parameters()]
+    assert names_r == names_m                                                   # same order -> same state indices
+    st_r, st_m = opt_r.state_dict()["state"], opt.state_dict()["state"]
+    assert set(st_r) == set(st_m) and len(st_m) == len(names_m) - 1             # every trainable parameter, not B
+    for i, n in enumerate(names_m):
+        if i in st_m:
+            assert torch.equal(st_m[i]["exp_avg"], st_r[i]["exp_avg"]), n
+            assert torch.equal(st_m[i]["exp_avg_sq"], st_r[i]["exp_avg_sq"]), n
 
 
 def test_reference_layout_file_with_prefix_and_other_head_loads_here(tmp_path):

@@ -76,6 +76,114 @@ def test_two_rank_bucketed_allreduce_matches_single_process(tmp_path):
         assert err < 1e-5, (k, err)                              # == gradient of the global-batch mean loss
 
 
+class _StandIn(torch.nn.Module):
+    """small torch model in place of the HIP one (which has no CPU path): same per-clip independence, several layers
+    so that the gradients fill several buckets in backward order"""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(3)
+        self.l0 = torch.nn.Linear(16, 48)
+        self.l1 = torch.nn.Linear(48, 48)
+        self.l2 = torch.nn.Linear(48, 48)
+        self.head = torch.nn.Linear(48, 5)
+        self.frozen = torch.nn.Parameter(torch.ones(3), requires_grad=False)      # like the Fourier matrix `B`
+
+    def forward(self, x):
+        h = torch.nn.functional.gelu(self.l0(x))
+        h = h + torch.nn.functional.gelu(self.l1(h))
+        h = h + torch.nn.functional.gelu(self.l2(h))
+        return self.head(h.mean(1))
+
+
+def _standin_batch():
+    g = torch.Generator().manual_seed(9)
+    return torch.rand(8, 6, 16, generator=g), torch.randint(0, 5, (8,), generator=g)
+
+
+def _trainstep_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    dmod = importlib.import_module("sl-hwgat_amd.dist")
+    tmod = importlib.import_module("sl-hwgat_amd.train")
+    model = _StandIn()
+    if rank != 0:
+        for p in model.parameters():
+            p.data.mul_(1.5)                                   # ranks start apart; broadcast_parameters must fix it
+    dmod.broadcast_parameters(model)
+    assert model.rank_salt == rank                              # every rank its own dropout stream (SURVEY 8e)
+    red = dmod.GradReducer(model.parameters(), bucket_bytes=4 << 10)
+    assert len(red.buckets) >= 3
+    red.trace = trace = []
+    # fires when the gradient of the FIRST layer lands, i.e. at the very end of a backward pass (registered after
+    # the reducer's own hook on the same parameter, so it runs after it)
+    model.l0.weight.register_post_accumulate_grad_hook(lambda _p: trace.append(("l0.weight grad", None, None)))
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=5e-4)
+    step = tmod.TrainStep(model, opt, red, micro_batch=2)
+    x, y = _standin_batch()
+    losses = []
+    for _ in range(2):                                          # second step: bucket reuse with accumulation
+        del trace[:]
+        step(x[rank * 4:(rank + 1) * 4], y[rank * 4:(rank + 1) * 4])
+        losses.append(float(step.loss))
+        # two micro-batches of 2 clips -> two backward passes; collectives go out in the LAST one only, from the hooks,
+        # and the buckets of the late layers are issued BEFORE backward has reached the first layer
+        ends = [i for i, e in enumerate(trace) if e[0] == "l0.weight grad"]
+        launches = [i for i, e in enumerate(trace) if e[0] == "launch"]
+        assert len(ends) == 2 and len(launches) == len(red.buckets), trace
+        assert all(trace[i][2] == "hook" for i in launches), trace          # none left for finish()
+        assert all(i > ends[0] for i in launches), trace                    # nothing reduced after the first pass
+        assert sum(i < ends[1] for i in launches) >= len(red.buckets) - 1, trace   # overlap with the rest of backward
+    torch.save({"params": {k: v.detach().clone() for k, v in model.state_dict().items()}, "losses": losses},
+               os.path.join(out_dir, f"ts{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_trainstep_with_micro_batches_equals_single_process_and_overlaps(tmp_path):
+    """the real train.TrainStep (micro-batch 2) + GradReducer + broadcast_parameters on 2 gloo ranks: after two
+    optimizer steps both ranks hold the parameters a single process gets from the global batch, and every bucket's
+    all-reduce was issued from inside backward (all but the last before backward reached the first layer)."""
+    port = _free_port()
+    mp.spawn(_trainstep_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    tmod = importlib.import_module("sl-hwgat_amd.train")
+    model = _StandIn()
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=5e-4)
+    step = tmod.TrainStep(model, opt, None, micro_batch=2)
+    x, y = _standin_batch()
+    for _ in range(2):
+        step(x, y)
+    r0 = torch.load(os.path.join(tmp_path, "ts0.pt"))
+    r1 = torch.load(os.path.join(tmp_path, "ts1.pt"))
+    for k, v in model.state_dict().items():
+        assert torch.equal(r0["params"][k], r1["params"][k]), k                # ranks stay bit-identical
+        assert torch.allclose(r0["params"][k], v, rtol=0, atol=2e-6), (k, (r0["params"][k] - v).abs().max())
+    # each rank reports the mean loss of ITS shard; their mean is the global-batch loss
+    assert abs(0.5 * (r0["losses"][-1] + r1["losses"][-1]) - float(step.loss)) < 1e-5
+
+
+def test_bench_counts_gpus_without_touching_the_runtime(monkeypatch):
+    """the spawning parent of `bench.py --gpus N` must not bring up HIP: devices are counted from the environment / KFD"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1,2")
+    assert bench.visible_gpu_count() == 3
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "GPU-abc")
+    assert bench.visible_gpu_count() == 1
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES")
+    monkeypatch.delenv("CUDA_VISIBLE_DEVICES", raising=False)
+    assert bench.visible_gpu_count() in (None, 0) or bench.visible_gpu_count() >= 1
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    body = src[src.index("def spawn_ranks"):src.index("def dry_run")]
+    assert "torch.cuda" not in body.replace("torch.cuda or HIP", "")
+
+
 def test_single_process_reducer_is_a_noop_wrapper():
     dmod = importlib.import_module("sl-hwgat_amd.dist")
     lin = torch.nn.Linear(8, 4)

@@ -19,7 +19,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for n in names:
         assert getattr(handle, n) is not None, n
     assert set(names) == set(hw._lib._SIGS), set(names) ^ set(hw._lib._SIGS)
-    assert handle.hwgat_abi_version() >= 1000
+    assert handle.hwgat_abi_version() == hw._lib.header_abi_version() >= 3000
 
 
 def test_state_dict_contract_matches_reference_keys():
