@@ -88,6 +88,78 @@ def host_cpu():
     return model, (len(cores) or (os.cpu_count() or 1)), usable
 
 
+def _cpu_cell_worker(idx, cpus, threads, barrier, queue, c, K, steps):
+    """one of N independent oracle processes of the host-saturating cell: pinned to its own block of CPUs, `threads`
+    intra-op threads, eval-mode fwd+bwd on B=2 clips of the workload's shape; reports (start, end, clips) of its timed
+    steps on the shared monotonic clock.  Never touches the GPU (torch CPU ops only)."""
+    try:
+        if cpus and hasattr(os, "sched_setaffinity"):
+            os.sched_setaffinity(0, cpus)
+        torch.set_num_threads(threads)
+        from oracle import hwgat_oracle as O
+        cfg = dict(kp_dim=c["C"], temporal_dim=c["T"], num_classes=c["nc"], embed_dim=c["d0"], num_kps=K)
+        params = {k: v.requires_grad_(k not in ("B", "pos_encoder.pe"))
+                  for k, v in O.synth_params(1, weight_std=0.02, **cfg).items()}
+        model = O.OracleHWGAT(params, num_kps=K, temporal_dim=c["T"], drop_rate=0.0)
+        g = torch.Generator().manual_seed(7 + idx)
+        x = torch.rand(2, c["T"], K, c["C"], generator=g)
+        y = torch.randint(0, c["nc"], (2,), generator=g)
+
+        def one():
+            for p in params.values():
+                p.grad = None
+            O.smoothed_cross_entropy(model.forward(x, thresholds=None), y).backward()
+        one()                                           # warm-up
+        barrier.wait(timeout=60)
+        t0 = time.monotonic()
+        for _ in range(steps):
+            one()
+        queue.put((idx, t0, time.monotonic(), 2 * steps))
+    except Exception as exc:                            # noqa: BLE001 -- reported, never fatal for the bench line
+        queue.put((idx, None, None, repr(exc)))
+
+
+def cpu_baseline_saturated(c, K, phys, usable, threads=16, steps=3, limit_s=25.0):
+    """The host-saturating cell of `cpu_baseline`: N = physical_cores / 16 independent oracle processes x 16 threads,
+    each pinned to its own block of CPUs (consecutive ids: one CCD group / NUMA node per process), started together;
+    aggregate clips/s = all clips of the timed steps / (last end - first start).  One 16-thread process leaves a
+    128-core host ~8x under-used; this is the CPU's best.  Returns None if it cannot run (too few cores)."""
+    import multiprocessing as mp
+    n_proc = min(max(1, min(phys, usable) // threads), 16)
+    if n_proc < 2:
+        return None
+    ctx = mp.get_context("spawn")                        # fresh interpreters: no GPU state is inherited
+    barrier, queue = ctx.Barrier(n_proc), ctx.Queue()
+    avail = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    procs = []
+    for i in range(n_proc):
+        cpus = set(avail[i * threads:(i + 1) * threads])
+        procs.append(ctx.Process(target=_cpu_cell_worker, args=(i, cpus, threads, barrier, queue, c, K, steps), daemon=True))
+    t_begin = time.perf_counter()
+    for p in procs:
+        p.start()
+    got = []
+    try:
+        while len(got) < n_proc and time.perf_counter() - t_begin < limit_s:
+            try:
+                got.append(queue.get(timeout=0.5))
+            except Exception:                            # noqa: BLE001 -- queue.Empty
+                if not any(p.is_alive() for p in procs) and queue.empty():
+                    break
+    finally:
+        for p in procs:                                  # exactly the processes started above
+            if p.is_alive():
+                p.terminate()
+        for p in procs:
+            p.join(timeout=5)
+    ok = [g for g in got if g[1] is not None]
+    if len(ok) != n_proc:
+        return {"error": f"{len(ok)} of {n_proc} workers finished within {limit_s} s", "details": [str(g[3]) for g in got if g[1] is None][:2]}
+    span = max(g[2] for g in ok) - min(g[1] for g in ok)
+    return {"clips_per_s": round(sum(g[3] for g in ok) / span, 3), "processes": n_proc, "threads_per_process": threads,
+            "timed_steps": steps, "seconds": round(time.perf_counter() - t_begin, 1)}
+
+
 def cpu_baseline(hgate=False, budget_s=45.0):
     """The oracle (CPU restatement of the reference, cross-checked at 0.95-1.10x the reference's own speed on the
     same cores: BASELINE.md section 3) timed on this box's host cores by the protocol of SURVEY.md 8d: clips of the
@@ -135,9 +207,10 @@ def cpu_baseline(hgate=False, budget_s=45.0):
             dt = time.perf_counter() - t0
             best = dt if (i == 1 or best is None) else best          # the second (warm) pass counts
         sweep[th] = round(2 / best, 3)
-        if time.perf_counter() - t_start > budget_s / 3:
+        if time.perf_counter() - t_start > budget_s / 4:
             break
     threads = max(sweep, key=sweep.get)
+    single_budget = budget_s - (14.0 if not hgate else 0.0)     # the host-saturating cell runs last, inside the budget
     torch.set_num_threads(threads)
     cells = {}
     for bsz in (2, 8):
@@ -148,7 +221,7 @@ def cpu_baseline(hgate=False, budget_s=45.0):
             est = None
             times = []
             for i in range(4):
-                if est is not None and time.perf_counter() - t_start + est > budget_s and i > 1:
+                if est is not None and time.perf_counter() - t_start + est > single_budget and i > 1:
                     break
                 for p in params.values():
                     p.grad = None
@@ -157,20 +230,28 @@ def cpu_baseline(hgate=False, budget_s=45.0):
                 O.smoothed_cross_entropy(out, y).backward()
                 times.append(time.perf_counter() - t0)
                 est = times[-1]
-                if i == 0 and time.perf_counter() - t_start + 3 * est > budget_s and bsz == 8 and name != "eval":
+                if i == 0 and time.perf_counter() - t_start + 3 * est > single_budget and bsz == 8 and name != "eval":
                     times = []
                     break
             timed = sorted(times[1:])
             if timed:
                 cells[f"B{bsz}_{name}"] = {"clips_per_s": round(bsz / timed[len(timed) // 2], 3), "timed_steps": len(timed)}
     best = max(cells, key=lambda k: cells[k]["clips_per_s"])
-    return {"value": cells[best]["clips_per_s"], "unit": "clips/s", "cores": threads, "kind": "port",
+    value, cores = cells[best]["clips_per_s"], threads
+    saturated = None
+    if not hgate:
+        left = budget_s - (time.perf_counter() - t_start)
+        saturated = cpu_baseline_saturated(c, K, phys, usable, limit_s=max(10.0, min(25.0, left + 8.0)))
+        if saturated and saturated.get("clips_per_s", 0.0) > value:
+            value, cores, best = saturated["clips_per_s"], saturated["processes"] * saturated["threads_per_process"], "host_saturated_eval_B2"
+    return {"value": value, "unit": "clips/s", "cores": cores, "kind": "port",
             "cpu_model": model_str, "physical_cores": phys, "usable_cpus": usable,
             "thread_sweep_clips_per_s": {str(k): v for k, v in sweep.items()},
             "sample": f"oracle (torch CPU restatement) fwd+bwd on clips of the same T={c['T']} K={K} C={c['C']} "
-                      f"d0={c['d0']} shape, B in (2, 8) x variants (eval, train drop 0, train drop 0.1 = the reference "
-                      f"default), median of up to 3 timed steps after 1 warm-up; value = fastest cell ({best})",
-            "cells": cells, "seconds": round(time.perf_counter() - t_start, 1)}
+                      f"d0={c['d0']} shape: single process, B in (2, 8) x variants (eval, train drop 0, train drop 0.1 = the "
+                      f"reference default), median of up to 3 timed steps after 1 warm-up; and the host-saturating cell "
+                      f"(physical_cores/16 pinned processes x 16 threads, eval B=2, aggregate); value = fastest ({best})",
+            "cells": cells, "host_saturated": saturated, "seconds": round(time.perf_counter() - t_start, 1)}
 
 
 def visible_gpu_count():
@@ -194,6 +275,69 @@ def visible_gpu_count():
         except (OSError, ValueError):
             return None
     return n
+
+
+def secondary_config3(hw, train_mod, dev, steps=10, warmup=3):
+    """BASELINE configs[2] (the headline shape with bf16 activations / bf16 MFMA linears, the HBM-bound variant) measured
+    in the SAME process right after the headline, so that every driver run of the default `python bench.py` also
+    records it: same full train step (zero_grad + fwd + loss + bwd + fused AdamW), train mode, inputs resident in HBM.
+    Returns the object stored under `secondary.config3_bf16`; the headline `value` is untouched by it."""
+    c = CFG
+    K = c["nW"] * 16
+    HF = hw.functional
+    torch.manual_seed(1001)
+    hp = hw.HWGATEParams({"src_len": c["T"], "num_class": c["nc"]}, c["C"], dev, num_kps=K, embed_dim=c["d0"])
+    model = hw.Model(*hp.get_model_params()).to(dev)
+    model.use_part_table(hw.part_table(c["J"], c["nW"]))
+    model.set_activation_dtype(torch.bfloat16)
+    model.train()
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=5e-4, fused=True)
+    step = train_mod.TrainStep(model, opt, None)
+    g = torch.Generator(device=dev).manual_seed(7)
+    x = torch.rand(c["B"], c["T"], c["J"], c["C"], device=dev, generator=g)
+    y = torch.randint(0, c["nc"], (c["B"],), device=dev, generator=g)
+    for _ in range(warmup):
+        step(x, y)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(x, y)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    HF.TIMERS = store = {}
+    for _ in range(2):                                   # two more steps with per-launch HIP events: kernel durations
+        step(x, y)
+    timers = HF.timers_summary()
+    HF.TIMERS = None
+    del store
+    rate = c["B"] * steps / elapsed
+    e_clip = c["T"] * K * c["d0"]
+    E = c["B"] * e_clip
+    bytes_clip = 364.0 * e_clip * 2                      # SURVEY 8d: (45 E s per block) x 8 + 4 E s, s = 2
+    flops_clip = 3.0 * (16.0 * sum(dep * c["d0"] * 2 ** i for i, dep in enumerate((2, 2, 4))) + 128.0 * 8) * e_clip
+    kern = {}
+    for name, bwd in (("hwgat_win_attn_fwd", False), ("hwgat_win_attn_bwd", True)):
+        n, ms = timers.get(name, (0, 0.0))
+        if n:
+            ach = attn_bytes(E, 2, bwd) / (ms / n * 1e-3)
+            kern[name] = {"bound": "hbm", "achieved": round(ach / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                          "frac": round(ach / HBM_PEAK, 4), "launches": n, "avg_us": round(ms / n * 1e3, 1)}
+    for name in ("hwgat_linear_nt_bf16", "hwgat_linear_tn_bf16"):
+        n, ms = timers.get(name, (0, 0.0))
+        n2, ms2 = timers.get(name + "_ex", (0, 0.0))
+        if n + n2:
+            kern[name] = {"launches_per_step": (n + n2) // 2, "ms_per_step": round((ms + ms2) / 2, 3)}
+    return {"value": round(rate, 2), "unit": "clips/s", "dtype": "bf16", "steps": steps, "warmup": warmup,
+            "ms_per_step": round(elapsed / steps * 1e3, 3),
+            "config": {"workload": f"BASELINE configs[2]: HWGAT train step (fwd+loss+bwd+AdamW), B={c['B']}/GPU T={c['T']} "
+                                   f"J={c['J']}->K={K} C={c['C']} d_model={c['d0']} depths[2,2,4] classes={c['nc']}, bf16 "
+                                   f"activations + bf16 MFMA linears, train-mode drop 0.1"},
+            "roofline_end_to_end": {"bound": "hbm", "achieved": round(rate * bytes_clip / 1e9, 1), "peak": HBM_PEAK / 1e9,
+                                    "unit": "GB/s", "frac": round(rate * bytes_clip / HBM_PEAK, 4), "bytes_per_clip": bytes_clip,
+                                    "other_roof": {"bound": "mfma", "achieved": round(rate * flops_clip / 1e12, 1), "peak": 2500.0,
+                                                   "unit": "TFLOP/s", "frac": round(rate * flops_clip / 2.5e15, 4)}},
+            "kernels": kern, "hip_kernel_ms_per_step": round(sum(v[1] for v in timers.values()) / 2, 3),
+            "loss": round(float(step.loss), 4)}
 
 
 def spawn_ranks(n, argv):
@@ -290,6 +434,8 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default: the config's)")
     ap.add_argument("--micro-batch", type=int, default=None, help="gradient-accumulation slice (clips)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary.config3_bf16 measurement the default run appends (same process, after the headline)")
     ap.add_argument("--no-kernel-timers", action="store_true", help="skip the per-launch HIP events (A/B runs)")
     ap.add_argument("--timer-every", type=int, default=4,
                     help="record the per-launch HIP events on every N-th step of the timed region (1 = every step)")
@@ -432,7 +578,7 @@ def main():
                 avg = ms / n * 1e-3
                 ach = attn_bytes(E, itemsize, bwd) / avg
                 kern[name] = {"bound": "hbm", "achieved": round(ach / 1e9, 1), "peak": HBM_PEAK / 1e9,
-                              "unit": "GB/s", "frac": round(ach / HBM_PEAK, 4), "traffic": None,
+                              "unit": "GB/s", "frac": round(ach / HBM_PEAK, 4), "traffic": None, "traffic_source": None,
                               "launches": n, "avg_us": round(avg * 1e6, 1),
                               "bytes_per_launch": attn_bytes(E, itemsize, bwd)}
         # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 correction + WRITE_SIZE,
@@ -447,6 +593,8 @@ def main():
                 rec = pmc.get(name + "_1seg", pmc.get(name))          # band fwd: the shipped 1-segment geometry
                 if rec and rec.get("E_bytes", pmc.get("E_bytes")) == E * itemsize:
                     kern[name]["traffic"] = rec["traffic_bytes_per_launch"]
+                    kern[name]["traffic_source"] = (f"stored rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE) of this kernel at this "
+                                                    f"shape, profiles/{fname} -- not measured in this run")
         except (OSError, KeyError):
             pass
         # linears: useful flops per step (fwd + dX + dW = 3 x 16*E*d_i per block) against the dense MFMA peak
@@ -513,6 +661,13 @@ def main():
             "hip_kernel_ms_per_step": round(hip_ms / n_timed, 3), "kernel_timer_steps": n_timed,
             "loss": round(loss, 4),
         }
+        default_run = (args.config == 2 and args.dtype == "f32" and args.model == "hwgate" and not args.eval_mode
+                       and not args.from_host and args.batch is None and args.micro_batch is None)
+        if world == 1 and default_run and not args.no_secondary:
+            # the headline's model / optimizer / saved activations go first; its numbers above are final
+            del step, opt, model
+            torch.cuda.empty_cache()
+            out["secondary"] = {"config3_bf16": secondary_config3(hw, train_mod, dev)}
         if world == 1 and not args.no_cpu_baseline and args.config != 5:
             # after the timed regions; the GPU is idle meanwhile
             out["cpu_baseline"] = cpu_baseline_wgate() if wgate else cpu_baseline(hgate=hgate)

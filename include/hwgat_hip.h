@@ -7,7 +7,9 @@
  * arithmetic it replaces.  Conventions for all entry points:
  *
  *   - plain device pointers + sizes, no torch types; the caller owns every
- *     buffer, nothing is allocated or freed here; no global mutable state;
+ *     buffer, nothing is allocated or freed here; no global mutable state and no
+ *     environment variables are read (the kernel lab's A/B switches exist only in
+ *     -DHWGAT_LAB builds, csrc/common.h);
  *   - `dtype` selects activation storage: HWGAT_F32 (0) or HWGAT_BF16 (1);
  *     parameters, statistics and all arithmetic are fp32;
  *   - `stream` is a hipStream_t passed as void*; launches are asynchronous and
@@ -162,6 +164,13 @@ int hwgat_debug_mfma16x16x4(const float* a, const float* b, float* out, void* st
  *   mean, rstd (B*n_tok) fp32 saved. */
 int hwgat_lnpool_fwd(const void* x, float* xhat_sum, float* mean, float* rstd,
                      int B, int n_tok, int d, int dtype, void* stream);
+/* Bit-reproducible form (the reference's eval() forward is deterministic, HWGATE.py:352-360): every block of the
+ * launch stores its partial sum into `partial` (B * hwgat_lnpool_partial_rows(B, n_tok) * d floats, caller-owned) and a
+ * second launch adds a clip's rows in index order into xhat_sum (which need NOT be zero on entry).  partial == NULL
+ * is hwgat_lnpool_fwd (fp32 atomics, summation order varies from run to run). */
+int hwgat_lnpool_partial_rows(int B, int n_tok);
+int hwgat_lnpool_fwd_det(const void* x, float* xhat_sum, float* mean, float* rstd,
+                         int B, int n_tok, int d, int dtype, float* partial, void* stream);
 /* backward: g (B, d) fp32 = dfeat * gamma / n_tok  ->  dx (B, n_tok, d) */
 int hwgat_lnpool_bwd(const float* g, const void* x, const float* mean, const float* rstd,
                      void* dx, int B, int n_tok, int d, int dtype, void* stream);

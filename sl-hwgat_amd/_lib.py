@@ -36,6 +36,8 @@ _SIGS = {
     "hwgat_band_attn_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "hwgat_debug_mfma16x16x4": [_P, _P, _P, _P],
     "hwgat_lnpool_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "hwgat_lnpool_partial_rows": [_I, _I],
+    "hwgat_lnpool_fwd_det": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
     "hwgat_lnpool_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "hwgat_lnpool_bwd_masked": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _U, _F, _P],
     "hwgat_unmerge_masked": [_P, _P, _P, _I, _I, _I, _I, _I, _U, _F, _P],

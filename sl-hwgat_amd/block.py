@@ -18,8 +18,6 @@ all dropout masks are recomputed (masks are a hash of (seed, element index)).
 
 backward (4 dW/db GEMMs, 4 dX GEMMs, attention backward, 2 LN backward launches).
 """
-import os
-
 import torch
 
 from . import functional as HF
@@ -29,8 +27,8 @@ from . import functional as HF
 # the kernels that produce their operands, so they fill the machine while the critical path runs
 # its HBM-bound kernels (attention backward, LayerNorm backward).  Joined before backward returns.
 # Measured on MI355X (config 2, fp32): 553.5 vs 552.4 clips/s -- no gain, both kinds of kernel use
-# persistent full-chip grids; kept as an opt-in (HWGAT_OVERLAP_DW=1), off by default.
-OVERLAP_DW = os.environ.get("HWGAT_OVERLAP_DW", "0") == "1"
+# persistent full-chip grids; kept as an opt-in module switch (set block.OVERLAP_DW = True), off by default.
+OVERLAP_DW = False
 _SIDE = {}
 
 
@@ -73,12 +71,21 @@ class _FusedBlock(torch.autograd.Function):
         # xc: the "carrier" the producing block handed over with x (or None).  It has no data (a 1-element tensor
         # expanded to x's shape); its only purpose is that THIS block's backward can return, as its gradient, the masked
         # copy of dx that the producing block needs in front of its fc2 dropout (cfg `up` = that dropout's seed).
-        bits, n_heads, shifted, p, seeds, kind, want_stats, merge_out, up, carry_out = cfg
+        bits, n_heads, shifted, p, seeds, kind, want_stats, merge_out, up, carry_out, book, deterministic = cfg
         ctx.set_materialize_grads(False)          # an unused carrier gradient arrives as None, not as a zero tensor
         B, F, K, d = x.shape
         dt = x.dtype                              # fp32, or bf16 activations with fp32 master weights
         cw = (lambda w: w) if dt == torch.float32 else (lambda w: w.to(dt))
         fuse = HF.can_fuse_row_stats(x)           # the producing epilogue delivers the LayerNorm statistics
+        if deterministic and fuse:
+            # the epilogue adds one partial (sum, sum of squares) per 256-wide column tile -- and per frame of a merged
+            # row -- with fp32 atomics: two addends onto zero commute exactly, more do not.  Bit-reproducible eval
+            # takes the separate statistics pass (and the merge pass) wherever a row would collect more than two.
+            tiles = -(-d // 256)
+            if tiles > 2:
+                fuse = False
+            elif merge_out and 2 * tiles > 2:
+                merge_out = False
         if m1 is None:
             m1, r1 = HF.ln_stats(x, n1w, n1b)
         qkv = HF.linear_nt_ln(x, wqkv, bqkv, (m1, r1, n1w, n1b))
@@ -102,8 +109,9 @@ class _FusedBlock(torch.autograd.Function):
         ctx.cfg = cfg
         ctx.merged = merged
         wide = d >= HF.MASK_ONCE_MIN_D
-        ctx.send_up = xc is not None and up is not None and p > 0.0 and wide
-        carry = bool(carry_out) and not merged and p > 0.0 and HF.MASK_ONCE >= 2 and wide
+        ctx.book = book
+        ctx.send_up = xc is not None and up is not None and p > 0.0 and wide and book is not None
+        carry = bool(carry_out) and not merged and p > 0.0 and HF.MASK_ONCE >= 2 and wide and book is not None
         oc = x.new_zeros(1).expand(out.shape) if carry else x.new_empty(0)
         if carry:
             ctx.mark_non_differentiable(mo, ro)
@@ -118,7 +126,8 @@ class _FusedBlock(torch.autograd.Function):
         up = ctx.cfg[8]
         B, F, K, d = x.shape
         dt = x.dtype
-        if not (dout.is_contiguous() and HF.carry_valid(dout, doutm)):
+        book = ctx.book
+        if not (dout.is_contiguous() and book is not None and book.valid(dout, doutm)):
             doutm = None                          # no carrier, or dout is not (only) the dx the masked copy was made from
         dout = dout.contiguous()
         if ctx.merged:                            # the gradient arrives in the merged layout: back to (B, F, K, d)
@@ -176,13 +185,15 @@ class _FusedBlock(torch.autograd.Function):
             dx, dxm = HF.ln_backward(d_xn, x, m1, r1, n1w, d_y, dn1w, dn1b, mask=up)
         else:
             dx = HF.ln_backward(d_xn, x, m1, r1, n1w, d_y, dn1w, dn1b)
-        HF.carry_register(dx, dxm)
+        if dxm is not None:
+            book.register(dx, dxm)
         dwq.join()        # every temporary above stays referenced until here, so the allocator cannot recycle it early
         return (dx, dxm, None, None, None, dn1w, dn1b, dwqkv, dbqkv, dwp, dbp, dn2w, dn2b, dw1, db1, dw2, db2, None)
 
 
 def fused_block(x, thr, blk, bits, n_heads, shifted, p, seeds, kind="win", stats=None, want_stats=False,
-                merge_out=False, return_stats=False, carrier=None, up=None, carry_out=False, return_carrier=None):
+                merge_out=False, return_stats=False, carrier=None, up=None, carry_out=False, return_carrier=None,
+                book=None, deterministic=False):
     """x (B,F,K,d) contiguous; `blk` holds norm1/attn.qkv/attn.proj/norm2/ff.fc1/ff.fc2.
     `kind`: 'win' = HWGATE part-window attention, 'blk' = HGATE block attention (thr must be None).
     `stats` = (mean, rstd) of the rows of x if the producer already has them; `want_stats`: have the fc2 epilogue produce
@@ -191,17 +202,21 @@ def fused_block(x, thr, blk, bits, n_heads, shifted, p, seeds, kind="win", stats
     `carrier` / `up` / `carry_out` (training with dropout): the dropout mask of a block's fc2 output is applied to the
     incoming gradient ONCE, by the LayerNorm backward of the block that consumes that output, instead of in two GEMM
     loaders: `carry_out` makes this block return a data-less carrier next to `out`; the consumer passes it as `carrier`
-    together with `up` = (this block's seeds[2], p) and returns the masked gradient as the carrier's gradient.
+    together with `up` = (this block's seeds[2], p) and returns the masked gradient as the carrier's gradient; both
+    sides need the same `book` (functional.CarryBook of this forward call), without one no carrier is made or used.
+    `deterministic`: bit-reproducible forward (eval mode): statistics / merged store stay in the epilogue only where a
+    row collects at most two atomic partials.
     Returns out, or (out, (mean, rstd) or None) with `return_stats`; with `carry_out` / `return_carrier` the carrier (or None) is appended."""
     m1, r1 = stats if stats is not None else (None, None)
-    if carrier is not None and (carrier.shape != x.shape or not x.requires_grad):
+    if carrier is not None and (carrier.shape != x.shape or not x.requires_grad or book is None):
         carrier = None
     out, mo, ro, oc = _FusedBlock.apply(
         x, carrier, thr, m1, r1, blk.norm1.weight, blk.norm1.bias, blk.attn.qkv.weight, blk.attn.qkv.bias,
         blk.attn.proj.weight, blk.attn.proj.bias, blk.norm2.weight, blk.norm2.bias,
         blk.ff.fc1.weight, blk.ff.fc1.bias, blk.ff.fc2.weight, blk.ff.fc2.bias,
         (bits, n_heads, shifted, float(p), tuple(int(s) for s in seeds), kind, bool(want_stats), bool(merge_out),
-         (int(up[0]), float(up[1])) if (up is not None and carrier is not None) else None, bool(carry_out)))
+         (int(up[0]), float(up[1])) if (up is not None and carrier is not None) else None, bool(carry_out),
+         book, bool(deterministic)))
     oc = oc if oc.numel() else None
     if return_carrier is None:
         return_carrier = bool(carry_out)

@@ -22,6 +22,8 @@ LIB = os.path.join(HERE, "libhwgat_hip.so")
 STAMP = LIB + ".stamp"
 HEADER = os.path.join(os.path.dirname(HERE), "include", "hwgat_hip.h")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-pass-failed"]
+if os.environ.get("HWGAT_LAB") == "1":       # kernel-lab build: compiles the A/B environment switches in (common.h)
+    FLAGS.append("-DHWGAT_LAB")
 # per-source extra flags (none at present)
 EXTRA = {}
 

@@ -507,7 +507,7 @@ extern "C" int hwgat_band_attn_bwd(const void* qkv, const void* dO, void* dqkv, 
     const int blocks = (int)((units + 3) / 4);
     // register-only form: PF 2 at 1 wave/SIMD 644 us, PF 2 at 2-3 waves/SIMD 630 us, PF 1 at 2 waves/SIMD 619 us (all issue-bound
     // alike); with the LDS transposes (XPOSE, the default; HWGAT_BAND_XPOSE=0 selects the register-only form) 514 us
-    static const bool xpose = !(getenv("HWGAT_BAND_XPOSE") && getenv("HWGAT_BAND_XPOSE")[0] == '0');
+    static const bool xpose = !(lab_env("HWGAT_BAND_XPOSE") && lab_env("HWGAT_BAND_XPOSE")[0] == '0');
 #define BWD_ARGS(T) (const T*)qkv, (const T*)dO, (T*)dqkv, maskrows, g, (int)units
 #define BWD(T)                                                                                       \
     if (hd == 32 && xpose) band_attn_bwd_k<T, 32, 1, 1, true><<<blocks, 256, 0, st>>>(BWD_ARGS(T)); \

@@ -582,8 +582,8 @@ extern "C" int hwgat_linear_nt_bf16_ex(const void* A, const void* W, const float
     }
     // outputs whose width is a multiple of 256: the 256x256 one-wave-per-SIMD kernel (gemm_bf16_nt256.hip: half the
     // L2 -> LDS stream of the 128x128 tile) over the 256-aligned rows; HWGAT_NT_KERNEL=old keeps the 128x128 kernel
-    static const bool nt_old = [] { const char* e = getenv("HWGAT_NT_KERNEL"); return e && e[0] == 'o'; }();
-    static const int nt256_min_k = [] { const char* e = getenv("HWGAT_NT256_MINK"); return e ? atoi(e) : 128; }();
+    static const bool nt_old = [] { const char* e = lab_env("HWGAT_NT_KERNEL"); return e && e[0] == 'o'; }();
+    static const int nt256_min_k = [] { const char* e = lab_env("HWGAT_NT256_MINK"); return e ? atoi(e) : 128; }();
     if (!nt_old && N % 256 == 0 && K >= nt256_min_k && M >= 256) {
         const int64_t m256 = M / 256 * 256;
         NtArgsB b = a;
@@ -646,7 +646,7 @@ extern "C" int hwgat_linear_tn_bf16(const void* A, const void* B, float* dW, flo
         HWGAT_LAUNCH_CHECK();
     }
     // dW at least 256 x 256: the 128x128-wave-tile kernel (gemm_bf16_tn256.hip); HWGAT_TN_KERNEL=old keeps this file's
-    static const bool tn_old = [] { const char* e = getenv("HWGAT_TN_KERNEL"); return e && e[0] == 'o'; }();
+    static const bool tn_old = [] { const char* e = lab_env("HWGAT_TN_KERNEL"); return e && e[0] == 'o'; }();
     // ... where its tiles fill the 256 CUs in whole rounds of equal blocks (tile count a divisor of 256: 1, 2, 4, 8 ...);
     // 3 or 12 tiles (the qkv weight) need three rounds of short M slices and lose to the 128x128 kernel:
     // stage 2 dWqkv 492 vs 454 us, stage 1 349 vs 272 (same box, tools/tn_lab.py)

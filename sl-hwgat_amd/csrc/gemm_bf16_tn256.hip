@@ -277,7 +277,7 @@ int hwgat_launch_tn256_bf16(TnArgsB a, hipStream_t st) {
     // the split count a multiple of 8 (split s lives on XCD s % 8) -- the rule of hwgat_launch_tn256 (gemm_f32_tn256.hip)
     auto gcd = [](int x, int y) { while (y) { int t = x % y; x = y; y = t; } return x; };
     const int r_min = n_tiles / gcd(n_tiles, 256);
-    static const int min_rounds = [] { const char* e = getenv("HWGAT_TN_ROUNDS"); return e ? atoi(e) : 1; }();
+    static const int min_rounds = [] { const char* e = lab_env("HWGAT_TN_ROUNDS"); return e ? atoi(e) : 1; }();
     int r = r_min;
     while (r < min_rounds) r += r_min;
     int64_t want = (int64_t)256 * r / n_tiles;
@@ -291,7 +291,7 @@ int hwgat_launch_tn256_bf16(TnArgsB a, hipStream_t st) {
     const int grid = ((a.n_split + 7) / 8) * 8 * n_tiles;
     const bool drop = a.pro_p > 0.f, ln = a.mean != nullptr;
     if (drop && ln) return HWGAT_ESHAPE;                         // not used by the model: the 128x128 kernel takes it
-    static const int nset = [] { const char* e = getenv("HWGAT_TN_NSET"); return e ? atoi(e) : 0; }();   // lab switch
+    static const int nset = [] { const char* e = lab_env("HWGAT_TN_NSET"); return e ? atoi(e) : 0; }();   // lab switch
     if (drop) {
         if (nset == 3) gemm_tn256_bf16_k<PRO_DROP, false, 3><<<grid, 256, 0, st>>>(a);
         else gemm_tn256_bf16_k<PRO_DROP, false, 2><<<grid, 256, 0, st>>>(a);

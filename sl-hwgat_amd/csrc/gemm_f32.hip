@@ -555,7 +555,7 @@ TnArgs tn_rows(TnArgs a, int64_t r0, int64_t rows) {
 // tile choice; HWGAT_GEMM_TILE=small|big overrides (A/B measurements only)
 int tile_override() {
     static const int v = [] {
-        const char* e = getenv("HWGAT_GEMM_TILE");
+        const char* e = lab_env("HWGAT_GEMM_TILE");
         return !e ? 0 : (e[0] == 's' ? 1 : (e[0] == 'b' ? 2 : (e[0] == 'k' ? 3 : (e[0] == 'm' ? 6 : (e[0] == 't' ? 7 : 0)))));
     }();
     return v;
@@ -572,7 +572,7 @@ int launch_tn(TnArgs a, hipStream_t st) {
     const int r_min = n_tiles / gcd(n_tiles, C::SLOTS);
     // one round where the tiles fill the slots (nearly) evenly -- a second round only doubles the atomic traffic at the
     // end of the M slices (see hwgat_launch_tn256); HWGAT_TN_ROUNDS=2 restores the round-1 rule for A/B runs
-    static const int min_rounds = [] { const char* e = getenv("HWGAT_TN_ROUNDS"); return e ? atoi(e) : 1; }();
+    static const int min_rounds = [] { const char* e = lab_env("HWGAT_TN_ROUNDS"); return e ? atoi(e) : 1; }();
     int r = r_min;
     while (r < min_rounds) r += r_min;
     int64_t want = (int64_t)C::SLOTS * r / n_tiles;
@@ -647,8 +647,8 @@ extern "C" int hwgat_linear_nt_f32_ex(const float* A, const float* W, const floa
     // 136.0, GELU-backward 102.7 -> 114.7, dropout-prologue dX 111.1 -> 124.3, projection 119.1 -> 126.4; stage 1 (K = 256
     // ... 768) +1 ... +10 %; stage 0 (N = 256, K = 128) +3 ... +5 %.  HWGAT_NT_KERNEL=old keeps everything on the 128x128
     // kernels, HWGAT_NT256_MINK moves the K threshold (A/B runs).
-    static const bool nt_old = [] { const char* e = getenv("HWGAT_NT_KERNEL"); return e && e[0] == 'o'; }();
-    static const int nt256_min_k = [] { const char* e = getenv("HWGAT_NT256_MINK"); return e ? atoi(e) : 128; }();
+    static const bool nt_old = [] { const char* e = lab_env("HWGAT_NT_KERNEL"); return e && e[0] == 'o'; }();
+    static const int nt256_min_k = [] { const char* e = lab_env("HWGAT_NT256_MINK"); return e ? atoi(e) : 128; }();
     if (!nt_old && tile_override() == 0 && N % 256 == 0 && K >= nt256_min_k && M >= 256) {
         const int64_t m256 = M / 256 * 256;
         NtArgs b = a;

@@ -202,7 +202,7 @@ int hwgat_launch_tn256(TnArgs a, hipStream_t st) {
     // 128.0, dW2 120.0 -> 123.2 TFLOP/s on one box; four rounds 104-119.  The split count has to stay a multiple of 8:
     // split s lives on XCD s % 8 (its tiles share the M slice through that XCD's L2), and 21 splits x 12 tiles put
     // 36 blocks on five of the XCDs' 32 CUs -- twice the time (measured).
-    static const int min_rounds = [] { const char* e = getenv("HWGAT_TN_ROUNDS"); return e ? atoi(e) : 1; }();
+    static const int min_rounds = [] { const char* e = lab_env("HWGAT_TN_ROUNDS"); return e ? atoi(e) : 1; }();
     int r = r_min;
     while (r < min_rounds) r += r_min;
     int64_t want = (int64_t)256 * r / n_tiles;

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void ln_bwd_k(const T* __restrict__ dy, const 
 template <typename T, int D>
 __global__ __launch_bounds__(256) void lnpool_fwd_k(const T* __restrict__ x, float* __restrict__ xhat_sum,
                                                     float* __restrict__ mean_o, float* __restrict__ rstd_o,
-                                                    int n_tok, int chunks) {
+                                                    int n_tok, int chunks, float* __restrict__ partial) {
     using M = RowMap<D>;
     __shared__ float red[4][D];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -229,8 +229,23 @@ __global__ __launch_bounds__(256) void lnpool_fwd_k(const T* __restrict__ x, flo
             for (int e = 0; e < 4; ++e) red[wv][(c * M::LPR + sub) * 4 + e] = acc[c][e];
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < D; i += 256)
-        atomicAdd(xhat_sum + (int64_t)b * D + i, red[0][i] + red[1][i] + red[2][i] + red[3][i]);
+    // `partial` (deterministic form): every block stores its own sum, lnpool_reduce_k adds the chunks of a clip in index
+    // order -- the same bits on every run; otherwise one fp32 atomic per block and channel (order varies run to run)
+    for (int i = threadIdx.x; i < D; i += 256) {
+        const float v = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+        if (partial) partial[(int64_t)blockIdx.x * D + i] = v;
+        else atomicAdd(xhat_sum + (int64_t)b * D + i, v);
+    }
+}
+
+// xhat_sum[b][i] = sum over the clip's chunks, in chunk order (fixed summation order)
+__global__ void lnpool_reduce_k(const float* __restrict__ partial, float* __restrict__ xhat_sum, int chunks, int d) {
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < d; i += blockDim.x) {
+        float s = 0.f;
+        for (int c = 0; c < chunks; ++c) s += partial[((int64_t)b * chunks + c) * d + i];
+        xhat_sum[(int64_t)b * d + i] = s;
+    }
 }
 
 // the upstream gradient of every token of clip b is the same vector g[b] (fp32)
@@ -421,12 +436,14 @@ extern "C" int hwgat_ln_bwd_masked(const void* dy, const void* x, const float* m
     return HWGAT_EDTYPE;
 }
 
-extern "C" int hwgat_lnpool_fwd(const void* x, float* xhat_sum, float* mean, float* rstd, int B, int n_tok,
-                                int d, int dtype, void* stream) {
+extern "C" int hwgat_lnpool_partial_rows(int B, int n_tok) { return (B <= 0 || n_tok <= 0) ? HWGAT_EINVAL : pool_chunks(B, n_tok); }
+
+extern "C" int hwgat_lnpool_fwd_det(const void* x, float* xhat_sum, float* mean, float* rstd, int B, int n_tok, int d,
+                                    int dtype, float* partial, void* stream) {
     if (!x || !xhat_sum || !mean || !rstd || B <= 0 || n_tok <= 0) return HWGAT_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int ch = pool_chunks(B, n_tok);
-#define GO(T, D) lnpool_fwd_k<T, D><<<B * ch, 256, 0, st>>>((const T*)x, xhat_sum, mean, rstd, n_tok, ch)
+#define GO(T, D) lnpool_fwd_k<T, D><<<B * ch, 256, 0, st>>>((const T*)x, xhat_sum, mean, rstd, n_tok, ch, partial)
 #define SW(T)                                  \
     switch (d) {                               \
         case 128: GO(T, 128); break;           \
@@ -439,7 +456,13 @@ extern "C" int hwgat_lnpool_fwd(const void* x, float* xhat_sum, float* mean, flo
     else if (dtype == HWGAT_BF16) { SW(bf16_t) }
     else return HWGAT_EDTYPE;
 #undef GO
+    if (partial) lnpool_reduce_k<<<B, 256, 0, st>>>(partial, xhat_sum, ch, d);
     HWGAT_LAUNCH_CHECK();
+}
+
+extern "C" int hwgat_lnpool_fwd(const void* x, float* xhat_sum, float* mean, float* rstd, int B, int n_tok, int d,
+                                int dtype, void* stream) {
+    return hwgat_lnpool_fwd_det(x, xhat_sum, mean, rstd, B, n_tok, d, dtype, nullptr, stream);
 }
 
 extern "C" int hwgat_lnpool_bwd_masked(const float* g, const void* x, const float* mean, const float* rstd, void* dx,

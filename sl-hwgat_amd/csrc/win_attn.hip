@@ -589,7 +589,7 @@ template <typename T, int HD>
 int launch_bwd(const void* qkv, const void* dO, void* dqkv, const uint32_t* mb, const float* thr,
                WinGeom g, int n_units, hipStream_t st) {
     if constexpr (HD == 128) {                               // two waves per unit, four waves per CU (see win_attn_bwd_split_k)
-        static const bool whole = [] { const char* e = getenv("HWGAT_ATTN_SPLIT"); return e && e[0] == '0'; }();
+        static const bool whole = [] { const char* e = lab_env("HWGAT_ATTN_SPLIT"); return e && e[0] == '0'; }();
         if (!whole) {
             const int blocks = min(n_units, 256 * (sizeof(T) == 2 ? 3 : 2));   // bf16 tiles: 44 KiB per workgroup
             if (thr)

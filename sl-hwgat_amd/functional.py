@@ -4,8 +4,6 @@ Every function here calls straight into libhwgat_hip.so through `_lib.call`;
 nothing falls back to torch arithmetic.  All activations are in the natural
 token order (B, F, K, d).
 """
-import os
-
 import torch
 
 from . import _lib
@@ -296,15 +294,22 @@ def temporal_merge(x):
 # ---------------------------------------------------------------- LN + pool
 class _LnPool(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, xc=None, up=None):
-        # xc / up: carrier of the masked gradient for the block that produced x (block.fused_block)
-        ctx.up = up if (xc is not None and up is not None and up[1] > 0.0) else None
+    def forward(ctx, x, gamma, beta, xc=None, up=None, book=None, deterministic=False):
+        # xc / up / book: carrier of the masked gradient for the block that produced x (block.fused_block)
+        ctx.up = up if (xc is not None and up is not None and up[1] > 0.0 and book is not None) else None
+        ctx.book = book
         B, d = x.shape[0], x.shape[-1]
         n_tok = x.numel() // (B * d)
-        hat = torch.zeros(B, d, device=x.device, dtype=torch.float32)
         mean = torch.empty(B * n_tok, device=x.device, dtype=torch.float32)
         rstd = torch.empty_like(mean)
-        call("hwgat_lnpool_fwd", ptr(x), ptr(hat), ptr(mean), ptr(rstd), B, n_tok, d, dtype_code(x), stream())
+        if deterministic:      # per-block partial sums added in index order: the same bits on every run
+            rows = _lib.lib().hwgat_lnpool_partial_rows(B, n_tok)
+            hat = torch.empty(B, d, device=x.device, dtype=torch.float32)
+            part = torch.empty(B * rows, d, device=x.device, dtype=torch.float32)
+            call("hwgat_lnpool_fwd_det", ptr(x), ptr(hat), ptr(mean), ptr(rstd), B, n_tok, d, dtype_code(x), ptr(part), stream())
+        else:
+            hat = torch.zeros(B, d, device=x.device, dtype=torch.float32)
+            call("hwgat_lnpool_fwd", ptr(x), ptr(hat), ptr(mean), ptr(rstd), B, n_tok, d, dtype_code(x), stream())
         hat_mean = hat / n_tok
         ctx.save_for_backward(x, gamma, mean, rstd, hat_mean)
         return hat_mean * gamma + beta
@@ -320,51 +325,77 @@ class _LnPool(torch.autograd.Function):
         dxm = torch.empty_like(x) if ctx.up is not None else None
         call("hwgat_lnpool_bwd_masked", ptr(g), ptr(x), ptr(mean), ptr(rstd), ptr(dx), B, n_tok, d,
              dtype_code(x), ptr(dxm), (ctx.up[0] if ctx.up else 0) & 0xFFFFFFFF, float(ctx.up[1]) if ctx.up else 0.0, stream())
-        carry_register(dx, dxm)
-        return dx, (dfeat * hat_mean).sum(0), dfeat.sum(0), dxm, None
+        if dxm is not None:
+            ctx.book.register(dx, dxm)
+        return dx, (dfeat * hat_mean).sum(0), dfeat.sum(0), dxm, None, None, None
 
 
-def ln_mean_pool(x, gamma, beta, carrier=None, up=None):
-    """final LayerNorm + mean over all tokens -> (B, d) fp32.  carrier / up: see block.fused_block (the last block's
-    fc2-dropout mask is applied to its incoming gradient here, once)."""
+def ln_mean_pool(x, gamma, beta, carrier=None, up=None, book=None, deterministic=False):
+    """final LayerNorm + mean over all tokens -> (B, d) fp32.  carrier / up / book: see block.fused_block (the last
+    block's fc2-dropout mask is applied to its incoming gradient here, once).  `deterministic`: fixed summation order
+    (two launches, no atomics), what eval() uses so that two forwards are bit-identical like the reference's."""
     xcont = x.contiguous()
-    if carrier is not None and (xcont is not x or carrier.shape != x.shape):
+    if carrier is not None and (xcont is not x or carrier.shape != x.shape or book is None):
         carrier = None
-    return _LnPool.apply(xcont, gamma, beta, carrier, up)
+    return _LnPool.apply(xcont, gamma, beta, carrier, up, book, bool(deterministic))
 
 
 # ---------------------------------------------------------------- fp32 MFMA linears
 PRO_NONE, PRO_LN, PRO_DROP, PRO_LN_FOLD = 0, 1, 2, 3
-# LayerNorm -> Linear pairs (norm1 -> qkv, norm2 -> fc1) run with the normalisation folded into the weights and
-# the GEMM epilogue (hwgat_ln_fold + pro 3) when the token count is whole tiles; HWGAT_LN_FOLD=0 keeps the
-# in-kernel normalising loader (pro 1) everywhere.
-LN_FOLD = os.environ.get("HWGAT_LN_FOLD", "1") != "0"
+# Formulation switches.  Plain module constants: the product reads no environment variables; the parity tests flip them
+# (monkeypatch) to compare the formulations against each other.
+# LayerNorm -> Linear pairs (norm1 -> qkv, norm2 -> fc1) run with the normalisation folded into the weights and the
+# GEMM epilogue (hwgat_ln_fold + pro 3) when the token count is whole tiles; False keeps the normalising loader (pro 1).
+LN_FOLD = True
 # Dropout masks in the backward pass: 0 = hashed in every GEMM loader that needs the masked gradient; 1 = the
 # LayerNorm backward that produces a gradient also writes its masked copy once (hwgat_ln_bwd_masked) for the block's own
-# projection dropout; 2 (default) = also across blocks, for the fc2 dropout of the block that produced this block's input.
-MASK_ONCE = int(os.environ.get("HWGAT_MASK_ONCE", "2"))
+# projection dropout; 2 = also across blocks, for the fc2 dropout of the block that produced this block's input.
+MASK_ONCE = 2
 # ... for blocks at least this wide: at d = 128 the extra E-sized write costs what the mask loaders cost there
 # (measured: WGATE, 8 blocks of d = 128, 1 468 -> 1 441 clips/s with masked copies everywhere)
-MASK_ONCE_MIN_D = int(os.environ.get("HWGAT_MASK_ONCE_MIN_D", "256"))
-# A masked copy handed to the producing block through a carrier is only valid if the gradient that block receives IS the
-# dx it was made from.  If the tensor has another consumer (an auxiliary loss on a block output, say) autograd adds that
-# gradient to dx -- in a new tensor, or in place -- and the copy would miss it.  The consumer therefore registers
-# (address, version counter) of its dx under the address of the masked copy; the producer uses the copy only if the
-# gradient it got still has exactly that address and version, and otherwise masks the real gradient in its loaders.
-_CARRY = {}
+MASK_ONCE_MIN_D = 256
 
 
-def carry_register(dx, dxm):
-    if dxm is not None:
-        _CARRY[dxm.data_ptr()] = (dx.data_ptr(), dx._version, tuple(dx.shape))
+class CarryBook:
+    """Validity records of the dropout-masked gradient copies of ONE forward call.
+
+    A masked copy handed to the producing block through a carrier is only valid if the gradient that block receives IS
+    the dx it was made from.  If the tensor has another consumer (an auxiliary loss on a block output, say) autograd adds
+    that gradient to dx -- in a new tensor, or in place -- and the copy would miss it.  The consumer therefore registers
+    (address, version counter, shape) of its dx under the address of the masked copy; the producer uses the copy only if
+    the gradient it got still has exactly that address and version, and otherwise masks the real gradient in its
+    loaders.  One book per forward call (held by the HandOver, referenced by the autograd nodes of that call): nothing is
+    shared between models or between two forwards of one model."""
+
+    def __init__(self):
+        self._rec = {}
+
+    def register(self, dx, dxm):
+        if dxm is not None:
+            self._rec[dxm.data_ptr()] = (dx.data_ptr(), dx._version, tuple(dx.shape))
+
+    def valid(self, dout, doutm):
+        """True iff `doutm` is the registered masked copy of exactly this `dout`"""
+        if doutm is None:
+            return False
+        rec = self._rec.pop(doutm.data_ptr(), None)
+        return rec is not None and rec == (dout.data_ptr(), dout._version, tuple(dout.shape))
 
 
-def carry_valid(dout, doutm):
-    """True iff `doutm` is the registered masked copy of exactly this `dout`"""
-    if doutm is None:
-        return False
-    rec = _CARRY.pop(doutm.data_ptr(), None)
-    return rec is not None and rec == (dout.data_ptr(), dout._version, tuple(dout.shape))
+class HandOver:
+    """What one block's epilogues produced for the next block of the same forward call: `of` = the tensor the values
+    belong to, `stats` = (mean, rstd) of its rows (from the fc2 epilogue), `carrier` / `up` = the data-less carrier of
+    the masked gradient and the (seed, p) of the dropout it masks, `plan[k]` = (produce output statistics, store merged)
+    for block k, `book` = the CarryBook of the call.  A local of Model.forward_features; never stored on the module."""
+
+    def __init__(self, last_block=-1, deterministic=False):
+        self.of = self.stats = self.carrier = self.up = None
+        self.plan = {}
+        self.last_block = last_block
+        self.deterministic = bool(deterministic)
+        self.book = CarryBook()
+
+
 EPI_BIAS, EPI_BIAS_DROP_RES, EPI_BIAS_GELU_DROP, EPI_GELU_BWD, EPI_NONE, EPI_BIAS_GELU_DROP_G, EPI_MUL_AUX = 0, 1, 2, 3, 4, 5, 6
 
 

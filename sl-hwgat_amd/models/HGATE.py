@@ -96,8 +96,8 @@ class Model(_base.Model):
         self.part_index = None                         # HGATE consumes the raw joints: no part table
         self.activation_dtype = torch.float32
         self.threshold_override = None
-        self.fused_linears = True
         self._drop_calls = 0
+        self.deterministic_eval = True
         if device is not None:
             self.to(device)
 

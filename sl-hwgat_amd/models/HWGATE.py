@@ -18,7 +18,6 @@ from typing import List, Optional
 
 import torch
 from torch import nn
-import torch.nn.functional as tF
 
 from .. import functional as HF
 from ..block import fused_block
@@ -123,10 +122,8 @@ class Model(nn.Module):
         self.part_index: Optional[torch.Tensor] = None           # set by use_part_table()
         self.activation_dtype = torch.float32
         self.threshold_override: Optional[List[float]] = None    # tests: inject train thresholds
-        self.fused_linears = True      # hand-written f32 MFMA linears with fused LN/GELU/dropout/residual
         self._drop_calls = 0
-        self._row_stats = None         # (tensor, (mean, rstd)) handed from a block's fc2 epilogue to the next block's LN1
-        self._plan = {}                # block index -> (produce output statistics, store merged)
+        self.deterministic_eval = True                            # eval(): fixed-order sums, bit-reproducible logits
         if device is not None:
             self.to(device)
 
@@ -145,16 +142,6 @@ class Model(nn.Module):
         return self
 
     # ------------------------------------------------------------ forward
-    def _linear(self, x, lin):
-        if x.dtype == torch.float32:
-            return tF.linear(x, lin.weight, lin.bias)
-        return tF.linear(x, lin.weight.to(x.dtype), lin.bias.to(x.dtype))
-
-    def _drop(self, x):
-        if self.training and self.drop_rate > 0.0:
-            return tF.dropout(x, self.drop_rate, True)
-        return x
-
     def _seeds(self, k):
         """three dropout-site seeds for block k of this forward call (host integers, no sync)"""
         # rank_salt: data-parallel ranks share torch's seed (identical initial weights) but must not share
@@ -163,41 +150,27 @@ class Model(nn.Module):
                 + getattr(self, "rank_salt", 0) * 0x27D4EB2F) & 0xFFFFFFFF
         return [(base + (k * 4 + s) * 0xC2B2AE35) & 0xFFFFFFFF for s in range(3)]
 
-    def _block(self, h, blk, n_heads, shifted, thr, k=0):
-        """one PartAttentionBlock.  Returns its output (B,F,K,d) -- or, for the last block of a stage when the fc2
-        epilogue can do it, already in the TemporalMerging layout (B,F/2,K,2d) (forward_features checks the shape)."""
-        if self.fused_linears:           # any token count: ragged tails get their own small GEMM launch
-            p = self.drop_rate if self.training else 0.0
-            h = h.contiguous()
-            # LayerNorm statistics of h handed over by the block that produced it, and what to ask of this one
-            rs = getattr(self, "_row_stats", None)
-            have = rs[1] if (rs is not None and rs[0] is h) else None
-            want, merge = getattr(self, "_plan", {}).get(k, (False, False))
-            # carrier of the dropout-masked gradient between consecutive blocks of a stage (block.fused_block)
-            cr = getattr(self, "_carrier", None)
-            carrier, up = (cr[1], cr[2]) if (cr is not None and cr[0] is h) else (None, None)
-            seeds = self._seeds(k)
-            out, st, oc = fused_block(h, thr, blk, self._mask_bits, n_heads, shifted, p, seeds, self._attn_kind,
-                                      stats=have, want_stats=want, merge_out=merge, return_stats=True,
-                                      carrier=carrier, up=up, carry_out=(want or k == getattr(self, "_last_block", -1)) and not merge,
-                                      return_carrier=True)
-            self._row_stats = (out, st) if st is not None else None
-            self._carrier = (out, oc, (seeds[2], p)) if oc is not None else None
-            return out
-        xn = HF.layer_norm(h, blk.norm1.weight, blk.norm1.bias)
-        qkv = self._linear(xn, blk.attn.qkv)
-        if self._attn_kind == "win":
-            o = HF.window_attention(qkv, self._mask_bits, thr, n_heads, shifted)
-        elif self._attn_kind == "blk":
-            o = HF.block_attention(qkv, self._mask_bits, n_heads, shifted)
-        else:
-            o = HF.band_attention(qkv, self._mask_bits, n_heads)
-        y = h + self._drop(self._linear(o, blk.attn.proj))
-        z = HF.layer_norm(y, blk.norm2.weight, blk.norm2.bias)
-        u = self._drop(tF.gelu(self._linear(z, blk.ff.fc1)))
-        return y + self._drop(self._linear(u, blk.ff.fc2))
+    def _block(self, h, blk, n_heads, shifted, thr, k, hand):
+        """one PartAttentionBlock (HWGATE.py:189-221) = one fused autograd node (block.fused_block).  `hand` is the
+        HandOver of THIS forward call: what the previous block's epilogues produced for this one (LayerNorm statistics of
+        h, the carrier of the dropout-masked gradient) goes in, what this block produces for the next one comes out --
+        explicit values held in a local of forward_features, nothing stored on the module.  Returns the block output
+        (B,F,K,d) -- or, for the last block of a stage when the fc2 epilogue can do it, already in the TemporalMerging
+        layout (B,F/2,K,2d) (forward_features checks the shape)."""
+        p = self.drop_rate if self.training else 0.0
+        h = h.contiguous()
+        have = hand.stats if hand.of is h else None
+        carrier, up = (hand.carrier, hand.up) if (hand.of is h and hand.carrier is not None) else (None, None)
+        want, merge = hand.plan.get(k, (False, False))
+        seeds = self._seeds(k)
+        out, st, oc = fused_block(h, thr, blk, self._mask_bits, n_heads, shifted, p, seeds, self._attn_kind,
+                                  stats=have, want_stats=want, merge_out=merge, return_stats=True,
+                                  carrier=carrier, up=up, carry_out=(want or k == hand.last_block) and not merge,
+                                  return_carrier=True, book=hand.book, deterministic=hand.deterministic)
+        hand.of, hand.stats, hand.carrier, hand.up = out, st, oc, ((seeds[2], p) if oc is not None else None)
+        return out
 
-    def forward_features(self, x):
+    def _embed(self, x):
         if x.dim() != 4 or x.shape[1] != self.temporal_dim or x.shape[3] != self.kp_dim:
             raise ValueError(f"expected (B,{self.temporal_dim},K,{self.kp_dim}) keypoints, got {tuple(x.shape)}")
         idx = None
@@ -210,18 +183,18 @@ class Model(nn.Module):
         if self.training:
             self._drop_calls += 1
         p_pe = self.drop_rate if (self.training and self.pe) else 0.0     # Dropout lives in PositionalEncoding
-        h = HF.embed(x, idx, self.B, pe, self.num_kps, self.activation_dtype, p_pe, self._seeds(63)[0])
-        k = 0
+        return HF.embed(x, idx, self.B, pe, self.num_kps, self.activation_dtype, p_pe, self._seeds(63)[0])
+
+    def forward_features(self, x):
+        h = self._embed(x)
         n_blocks = sum(len(st.blocks) for st in self.layers)
-        self._row_stats = None
-        self._carrier = None
-        self._last_block = n_blocks - 1
-        HF._CARRY.clear()                 # registrations of a backward pass that never reached their producer
-        self._plan, kk = {}, 0
+        hand = HF.HandOver(last_block=n_blocks - 1, deterministic=self.deterministic_eval and not self.training)
+        kk = 0
         for i, stage in enumerate(self.layers):          # every block but the last feeds a LayerNorm; stage ends merge
             for j in range(len(stage.blocks)):
-                self._plan[kk] = (kk < n_blocks - 1, j == len(stage.blocks) - 1 and i < self.num_layers - 1)
+                hand.plan[kk] = (kk < n_blocks - 1, j == len(stage.blocks) - 1 and i < self.num_layers - 1)
                 kk += 1
+        k = 0
         for i, stage in enumerate(self.layers):
             for j, blk in enumerate(stage.blocks):
                 thr = None
@@ -230,15 +203,14 @@ class Model(nn.Module):
                         thr = torch.full((1,), float(self.threshold_override[k]), device=x.device)
                     else:
                         thr = torch.rand(1, device=x.device)      # device RNG, no host sync
-                h = self._block(h, blk, self.num_heads[i], j % 2 == 1, thr, k)
+                h = self._block(h, blk, self.num_heads[i], j % 2 == 1, thr, k, hand)
                 k += 1
             if i < self.num_layers - 1 and h.shape[-1] == self.embed_dim * 2 ** i:
-                h = HF.temporal_merge(h)                  # the fc2 epilogue could not store merged (bf16 / ragged M)
-        self._row_stats = None
-        cr, self._carrier = self._carrier, None
-        if cr is not None and cr[0] is h:
-            return HF.ln_mean_pool(h, self.norm.weight, self.norm.bias, carrier=cr[1], up=cr[2])
-        return HF.ln_mean_pool(h, self.norm.weight, self.norm.bias)
+                h = HF.temporal_merge(h)                  # the fc2 epilogue could not store merged (ragged M)
+        if hand.of is h and hand.carrier is not None:
+            return HF.ln_mean_pool(h, self.norm.weight, self.norm.bias, carrier=hand.carrier, up=hand.up, book=hand.book,
+                                   deterministic=hand.deterministic)
+        return HF.ln_mean_pool(h, self.norm.weight, self.norm.bias, deterministic=hand.deterministic)
 
     def forward(self, x):
         feat = self.forward_features(x)

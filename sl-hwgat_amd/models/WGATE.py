@@ -81,25 +81,19 @@ class Model(_base.Model):
         self.part_index = None
         self.activation_dtype = torch.float32
         self.threshold_override = None
-        self.fused_linears = True
         self._drop_calls = 0
+        self.deterministic_eval = True
         if device is not None:
             self.to(device)
 
     def forward_features(self, x):
-        if x.dim() != 4 or x.shape[1] != self.temporal_dim or x.shape[3] != self.kp_dim:
-            raise ValueError(f"expected (B,{self.temporal_dim},K,{self.kp_dim}) keypoints, got {tuple(x.shape)}")
-        idx = None
-        if x.shape[2] != self.num_kps:
-            if self.part_index is None:
-                raise ValueError(f"got {x.shape[2]} joints, model has {self.num_kps} slots and no part table")
-            idx = self.part_index
-        x = x.contiguous().float()
-        pe = self.pos_encoder.pe.view(self.temporal_dim, self.embed_dim) if self.pe else None
-        if self.training:
-            self._drop_calls += 1
-        p_pe = self.drop_rate if (self.training and self.pe) else 0.0     # Dropout lives in PositionalEncoding
-        h = HF.embed(x, idx, self.B, pe, self.num_kps, self.activation_dtype, p_pe, self._seeds(63)[0])
+        h = self._embed(x)
+        hand = HF.HandOver(last_block=self.depths - 1, deterministic=self.deterministic_eval and not self.training)
+        for k in range(self.depths):                   # every block but the last feeds the next block's LayerNorm
+            hand.plan[k] = (k < self.depths - 1, False)
         for k, blk in enumerate(self.layers):          # PartAttentionBlock.forward, WGATE.py:150-160
-            h = self._block(h, blk, self.num_heads, False, None, k)
-        return HF.ln_mean_pool(h, self.norm.weight, self.norm.bias)
+            h = self._block(h, blk, self.num_heads, False, None, k, hand)
+        if hand.of is h and hand.carrier is not None:
+            return HF.ln_mean_pool(h, self.norm.weight, self.norm.bias, carrier=hand.carrier, up=hand.up, book=hand.book,
+                                   deterministic=hand.deterministic)
+        return HF.ln_mean_pool(h, self.norm.weight, self.norm.bias, deterministic=hand.deterministic)

@@ -87,7 +87,7 @@ def test_one_clip_bf16_within_the_contract_of_the_fp32_reference(name):
             continue
         worst = max(worst, abs(prm.grad.double().norm().item() - fx[key][0]) / max(fx[key][0], 1e-12))
     print(name, "bf16 worst grad-norm rel err", worst)
-    assert worst < 0.1          # bf16 rounding accumulates through 8 blocks of backward: norms to 10 %
+    assert worst < 0.05         # coarse digest only; the entry-wise bf16 bound is test_batch_8_bf16_all_gradients_...
 
 
 def test_headline_batch_64_clip_0_equals_the_reference():
@@ -140,3 +140,69 @@ def test_batch_8_all_gradients_equal_the_oracle():
         worst = max(worst, e)
         assert e < 2 * TOL, (name, e)
     print("B=8 worst full-gradient rel err", worst)
+
+
+# measured on MI355X (round 3, printed by the test): worst per-parameter relative L2 error of a bf16 gradient against the
+# fp64 oracle at B=8, eval-mode fwd+bwd -- the bound is 3x that, replacing the old "norm within 10 %" check
+BF16_GRAD_TOL = 4.5e-2
+
+
+def test_batch_8_bf16_all_gradients_entrywise_against_the_oracle():
+    """BASELINE configs[2] arithmetic (bf16 activations, bf16 MFMA linears, fp32 master weights and accumulation) at
+    B=8 of the headline width: EVERY parameter gradient, all entries, against the fp64 oracle -- a mis-scaled or
+    misplaced bf16 dW / db / dgamma cannot pass (a factor 2 is a relative error of 1, a swapped tile ~1.4).  Eval-mode
+    fwd+bwd: under bf16 a probability within rounding of a train-mode threshold flips the selector of HWGATE.py:94-100,
+    which is a discontinuity of the function, not an arithmetic error."""
+    fx = load_fixture("cfg2_clip.npz")
+    model, cfg, params = build(fx, torch.bfloat16)
+    g = torch.Generator().manual_seed(321)
+    x = torch.rand(8, *fx["x"].shape[1:], generator=g)
+    y = torch.randint(0, cfg["num_classes"], (8,), generator=g)
+    model.eval()
+    out = model(x.to(DEV))
+    O.smoothed_cross_entropy(out.float(), y.to(DEV)).backward()
+    ref_p = {k: v.double().requires_grad_(k not in ("B", "pos_encoder.pe")) for k, v in params.items()}
+    oracle = O.OracleHWGAT(ref_p, num_kps=cfg["num_kps"], temporal_dim=cfg["temporal_dim"])
+    ref = oracle.forward(x.double())
+    O.smoothed_cross_entropy(ref, y).backward()
+    assert rel_err(out.float().detach().cpu(), ref.detach()) < BF16_TOL
+    errs = {}
+    for name, prm in model.named_parameters():
+        if prm.grad is None:
+            continue
+        errs[name] = rel_err(prm.grad.float().cpu(), ref_p[name].grad)
+    worst = max(errs, key=errs.get)
+    print("B=8 bf16 worst full-gradient rel err", worst, errs[worst], "median", sorted(errs.values())[len(errs) // 2])
+    assert len(errs) == sum(1 for k in ref_p if ref_p[k].requires_grad)
+    for name, e in errs.items():
+        assert e < BF16_GRAD_TOL, (name, e)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_eval_forward_is_bit_reproducible_at_the_headline_shape(dtype):
+    """the reference's eval() forward is deterministic (plain ATen, HWGATE.py:352-360): two eval forwards
+    of the B=64 headline batch must be torch.equal here too.  eval() takes the fixed-order pooled sum
+    (hwgat_lnpool_fwd_det) and keeps epilogue statistics only where a row collects <= 2 atomic partials."""
+    fx = load_fixture("cfg2_clip.npz")
+    model, cfg, _ = build(fx, dtype)
+    model.eval()
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(64, *fx["x"].shape[1:], generator=g).to(DEV)
+    with torch.no_grad():
+        a = model(x)
+        junk = torch.randn(1 << 24, device=DEV).sum()           # unrelated work in between: different block timing
+        b = model(x)
+        c = model(x)
+    assert junk.isfinite()
+    assert torch.equal(a, b) and torch.equal(a, c)
+    # the wide model (d0 = 256: stage widths 256 / 512 / 1024, merged 512-wide rows) takes the separate statistics
+    # passes where more than two partials would meet
+    fx5 = load_fixture("cfg5_clip.npz")
+    model5, cfg5, _ = build(fx5, dtype)
+    model5.eval()
+    x5 = torch.from_numpy(fx5["x"]).to(DEV).repeat(4, 1, 1, 1)
+    with torch.no_grad():
+        a5, b5 = model5(x5), model5(x5)
+    assert torch.equal(a5, b5)
+    tol = TOL if dtype == torch.float32 else BF16_TOL
+    assert rel_err(a5[:1].float().cpu(), fx5["eval.logits"]) < tol            # and still the reference's numbers

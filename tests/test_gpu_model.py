@@ -7,6 +7,7 @@ import pytest
 import torch
 
 from oracle import hwgat_oracle as O
+from libgemm_path import use_library_linears
 from helpers import load_fixture, cfg_of, oracle_from_fixture, rel_err, grad_digest_check, sub, natural
 
 pytestmark = pytest.mark.gpu
@@ -35,7 +36,8 @@ def build(fx, drop=0.0):
     wstd = float(fx["wstd"]) if "wstd" in fx else 0.08
     res = model.load_state_dict(O.synth_params(seed, weight_std=wstd, **cfg), strict=False)
     assert not res.unexpected_keys and all(k.endswith("attn_mask") for k in res.missing_keys)
-    model.fused_linears = FUSED
+    if not FUSED:
+        use_library_linears(model)
     return model.to(DEV), cfg
 
 
@@ -52,8 +54,8 @@ def test_eval_logits_and_block_taps_cfg1():
     orig = model._block
     counter = {"k": 0}
 
-    def tapped(h, blk, n_heads, shifted, thr, k=0):
-        out = orig(h, blk, n_heads, shifted, thr, k)
+    def tapped(*a):
+        out = orig(*a)
         taps[f"block{counter['k']}"] = out.detach()
         counter["k"] += 1
         return out
@@ -131,7 +133,8 @@ def test_fresh_inputs_vs_oracle_and_raw_joint_path():
     hp.drop_rate = 0.0
     model = hw.Model(*hp.get_model_params())
     model.load_state_dict(params, strict=False)
-    model.fused_linears = FUSED
+    if not FUSED:
+        use_library_linears(model)
     idx = hw.part_table(27, nW)
     model.use_part_table(idx).eval()
     g = torch.Generator().manual_seed(2)
@@ -248,10 +251,12 @@ def test_dropout_mask_applied_once_by_the_consumer_equals_hashing_in_the_loaders
         for mode in (0, 2):
             HF.MASK_ONCE = mode
             x = x0.clone().requires_grad_(True)
+            book = HF.CarryBook()
             h, st, oc = fb.fused_block(x, thr, blks[0], model._mask_bits, nH, False, p, s0, want_stats=True,
-                                       return_stats=True, carry_out=True)
+                                       return_stats=True, carry_out=True, book=book)
             assert (oc is not None) == (mode == 2)
-            out = fb.fused_block(h, thr, blks[1], model._mask_bits, nH, True, p, s1, stats=st, carrier=oc, up=(s0[2], p))
+            out = fb.fused_block(h, thr, blks[1], model._mask_bits, nH, True, p, s1, stats=st, carrier=oc, up=(s0[2], p),
+                                 book=book)
             if g is None:
                 g = torch.randn_like(out)
             out.backward(g)
@@ -295,9 +300,11 @@ def test_masked_copy_is_dropped_when_the_block_output_has_another_consumer():
         for mode in (0, 2):
             HF.MASK_ONCE = mode
             x = x0.clone().requires_grad_(True)
+            book = HF.CarryBook()
             h, st, oc = fb.fused_block(x, thr, blks[0], model._mask_bits, nH, False, p, s0, want_stats=True,
-                                       return_stats=True, carry_out=True)
-            out = fb.fused_block(h, thr, blks[1], model._mask_bits, nH, True, p, s1, stats=st, carrier=oc, up=(s0[2], p))
+                                       return_stats=True, carry_out=True, book=book)
+            out = fb.fused_block(h, thr, blks[1], model._mask_bits, nH, True, p, s1, stats=st, carrier=oc, up=(s0[2], p),
+                                 book=book)
             if g is None:
                 g = torch.randn_like(out)
             ((out * g).sum() + (h * wext).sum()).backward()             # h has a second consumer

@@ -10,6 +10,7 @@ import pytest
 import torch
 
 from oracle import wgat_oracle as OW
+from libgemm_path import use_library_linears
 from helpers import load_fixture, wgate_oracle_from_fixture, rel_err, grad_digest_check
 
 pytestmark = pytest.mark.gpu
@@ -163,7 +164,8 @@ def _model_from_fixture(fx, dtype=torch.float32):
 def test_model_matches_reference_fixture(name, fused):
     fx = load_fixture(name)
     model, _ = _model_from_fixture(fx)
-    model.fused_linears = fused
+    if not fused:
+        use_library_linears(model)
     x = torch.from_numpy(fx["x"]).to(DEV)
     y = torch.from_numpy(fx["y"]).to(DEV)
     crit = importlib.import_module("sl-hwgat_amd.train").SmoothedCrossEntropyLoss()
