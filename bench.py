@@ -119,15 +119,20 @@ def _cpu_cell_worker(idx, cpus, threads, barrier, queue, c, K, steps):
         queue.put((idx, None, None, repr(exc)))
 
 
-def cpu_baseline_saturated(c, K, phys, usable, threads=16, steps=3, limit_s=25.0):
-    """The host-saturating cell of `cpu_baseline`: N = physical_cores / 16 independent oracle processes x 16 threads,
-    each pinned to its own block of CPUs (consecutive ids: one CCD group / NUMA node per process), started together;
-    aggregate clips/s = all clips of the timed steps / (last end - first start).  One 16-thread process leaves a
-    128-core host ~8x under-used; this is the CPU's best.  Returns None if it cannot run (too few cores)."""
+def cpu_baseline_saturated(c, K, phys, usable, threads=None, steps=3, limit_s=25.0, max_proc=4):
+    """The host-saturating cell of `cpu_baseline`: N independent oracle processes that together occupy every physical
+    core -- N = min(4, physical_cores / 16), physical_cores / N threads each (4 x 32 on a 128-core host; the GPU box
+    admits at most 6 processes next to an open GPU context, and a freshly started torch process counts as one, so N
+    stays at 4) -- each pinned to its own block of CPUs (consecutive ids: one group of CCDs / NUMA node per process),
+    started together; aggregate clips/s = all clips of the timed steps / (last end - first start).  One 16-thread
+    process leaves a 128-core host ~8x under-used; this is the CPU's best.  Returns None if it cannot run (too few cores)."""
     import multiprocessing as mp
-    n_proc = min(max(1, min(phys, usable) // threads), 16)
+    cores = min(phys, usable)
+    n_proc = min(max_proc, max(1, cores // 16)) if threads is None else min(max_proc, max(1, cores // threads))
     if n_proc < 2:
         return None
+    if threads is None:
+        threads = cores // n_proc
     ctx = mp.get_context("spawn")                        # fresh interpreters: no GPU state is inherited
     barrier, queue = ctx.Barrier(n_proc), ctx.Queue()
     avail = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
