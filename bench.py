@@ -88,7 +88,7 @@ def host_cpu():
     return model, (len(cores) or (os.cpu_count() or 1)), usable
 
 
-def _cpu_cell_worker(idx, cpus, threads, barrier, queue, c, K, steps):
+def _cpu_cell_worker(idx, cpus, threads, barrier, queue, c, K, steps, go):
     """one of N independent oracle processes of the host-saturating cell: pinned to its own block of CPUs, `threads`
     intra-op threads, eval-mode fwd+bwd on B=2 clips of the workload's shape; reports (start, end, clips) of its timed
     steps on the shared monotonic clock.  Never touches the GPU (torch CPU ops only)."""
@@ -109,6 +109,7 @@ def _cpu_cell_worker(idx, cpus, threads, barrier, queue, c, K, steps):
             for p in params.values():
                 p.grad = None
             O.smoothed_cross_entropy(model.forward(x, thresholds=None), y).backward()
+        go.wait(timeout=120)                            # the parent finishes its single-process cells first
         one()                                           # warm-up
         barrier.wait(timeout=60)
         t0 = time.monotonic()
@@ -119,50 +120,67 @@ def _cpu_cell_worker(idx, cpus, threads, barrier, queue, c, K, steps):
         queue.put((idx, None, None, repr(exc)))
 
 
-def cpu_baseline_saturated(c, K, phys, usable, threads=None, steps=3, limit_s=25.0, max_proc=4):
+class _SaturatedCell:
     """The host-saturating cell of `cpu_baseline`: N independent oracle processes that together occupy every physical
     core -- N = min(4, physical_cores / 16), physical_cores / N threads each (4 x 32 on a 128-core host; the GPU box
     admits at most 6 processes next to an open GPU context, and a freshly started torch process counts as one, so N
-    stays at 4) -- each pinned to its own block of CPUs (consecutive ids: one group of CCDs / NUMA node per process),
-    started together; aggregate clips/s = all clips of the timed steps / (last end - first start).  One 16-thread
-    process leaves a 128-core host ~8x under-used; this is the CPU's best.  Returns None if it cannot run (too few cores)."""
-    import multiprocessing as mp
-    cores = min(phys, usable)
-    n_proc = min(max_proc, max(1, cores // 16)) if threads is None else min(max_proc, max(1, cores // threads))
-    if n_proc < 2:
-        return None
-    if threads is None:
-        threads = cores // n_proc
-    ctx = mp.get_context("spawn")                        # fresh interpreters: no GPU state is inherited
-    barrier, queue = ctx.Barrier(n_proc), ctx.Queue()
-    avail = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
-    procs = []
-    for i in range(n_proc):
-        cpus = set(avail[i * threads:(i + 1) * threads])
-        procs.append(ctx.Process(target=_cpu_cell_worker, args=(i, cpus, threads, barrier, queue, c, K, steps), daemon=True))
-    t_begin = time.perf_counter()
-    for p in procs:
-        p.start()
-    got = []
-    try:
-        while len(got) < n_proc and time.perf_counter() - t_begin < limit_s:
-            try:
-                got.append(queue.get(timeout=0.5))
-            except Exception:                            # noqa: BLE001 -- queue.Empty
-                if not any(p.is_alive() for p in procs) and queue.empty():
-                    break
-    finally:
-        for p in procs:                                  # exactly the processes started above
-            if p.is_alive():
-                p.terminate()
-        for p in procs:
-            p.join(timeout=5)
-    ok = [g for g in got if g[1] is not None]
-    if len(ok) != n_proc:
-        return {"error": f"{len(ok)} of {n_proc} workers finished within {limit_s} s", "details": [str(g[3]) for g in got if g[1] is None][:2]}
-    span = max(g[2] for g in ok) - min(g[1] for g in ok)
-    return {"clips_per_s": round(sum(g[3] for g in ok) / span, 3), "processes": n_proc, "threads_per_process": threads,
-            "timed_steps": steps, "seconds": round(time.perf_counter() - t_begin, 1)}
+    stays at 4) -- each pinned to its own block of CPUs (consecutive ids: one group of CCDs / NUMA node per process).
+    `start()` launches the interpreters (they import torch and build the oracle, then sleep on an event, so the
+    single-process cells are not disturbed); `run()` releases them together and returns the aggregate clips/s = all clips
+    of the timed steps / (last end - first start).  One 16-thread process leaves a 128-core host ~8x under-used; this is
+    the CPU's best."""
+
+    def __init__(self, c, K, phys, usable, threads=None, steps=3, max_proc=4):
+        import multiprocessing as mp
+        cores = min(phys, usable)
+        self.n_proc = min(max_proc, max(1, cores // (threads or 16)))
+        self.threads = threads or (cores // max(self.n_proc, 1))
+        self.steps, self.procs = steps, []
+        if self.n_proc < 2:
+            return
+        ctx = mp.get_context("spawn")                    # fresh interpreters: no GPU state is inherited
+        self.barrier, self.queue, self.go = ctx.Barrier(self.n_proc), ctx.Queue(), ctx.Event()
+        avail = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+        for i in range(self.n_proc):
+            cpus = set(avail[i * self.threads:(i + 1) * self.threads])
+            self.procs.append(ctx.Process(target=_cpu_cell_worker, daemon=True,
+                                          args=(i, cpus, self.threads, self.barrier, self.queue, c, K, steps, self.go)))
+
+    def start(self):
+        for p in self.procs:
+            p.start()
+        return self
+
+    def run(self, limit_s=40.0):
+        if not self.procs:
+            return None
+        t_begin = time.perf_counter()
+        self.go.set()
+        got = []
+        try:
+            while len(got) < self.n_proc and time.perf_counter() - t_begin < limit_s:
+                try:
+                    got.append(self.queue.get(timeout=0.5))
+                except Exception:                        # noqa: BLE001 -- queue.Empty
+                    if not any(p.is_alive() for p in self.procs) and self.queue.empty():
+                        break
+        finally:
+            for p in self.procs:                         # exactly the processes started above
+                if p.is_alive():
+                    p.terminate()
+            for p in self.procs:
+                p.join(timeout=5)
+        ok = [g for g in got if g[1] is not None]
+        if len(ok) != self.n_proc:
+            return {"error": f"{len(ok)} of {self.n_proc} workers finished within {limit_s:.0f} s",
+                    "details": [str(g[3]) for g in got if g[1] is None][:2]}
+        span = max(g[2] for g in ok) - min(g[1] for g in ok)
+        return {"clips_per_s": round(sum(g[3] for g in ok) / span, 3), "processes": self.n_proc,
+                "threads_per_process": self.threads, "timed_steps": self.steps, "seconds": round(time.perf_counter() - t_begin, 1)}
+
+
+def cpu_baseline_saturated(c, K, phys, usable, threads=None, steps=3, limit_s=40.0, max_proc=4):
+    return _SaturatedCell(c, K, phys, usable, threads, steps, max_proc).start().run(limit_s)
 
 
 def cpu_baseline(hgate=False, budget_s=45.0):
@@ -194,6 +212,7 @@ def cpu_baseline(hgate=False, budget_s=45.0):
     if hgate:
         variants = variants[:1]                      # the HGATE oracle models neither threshold nor dropout
     t_start = time.perf_counter()
+    sat_cell = None if hgate else _SaturatedCell(c, K, phys, usable).start()   # interpreters come up meanwhile, then sleep
     # thread count: SURVEY 8d says "all physical cores", but on a 128-core host the small per-window ATen ops run
     # SLOWER with 128 threads than with 16-32 (first box measured: 0.9 vs 5.5 clips/s).  The baseline must be the
     # CPU's best, so a short sweep on the cheapest cell picks the thread count; every trial is recorded.
@@ -215,7 +234,7 @@ def cpu_baseline(hgate=False, budget_s=45.0):
         if time.perf_counter() - t_start > budget_s / 4:
             break
     threads = max(sweep, key=sweep.get)
-    single_budget = budget_s - (14.0 if not hgate else 0.0)     # the host-saturating cell runs last, inside the budget
+    single_budget = budget_s - (10.0 if not hgate else 0.0)     # the host-saturating cell runs last
     torch.set_num_threads(threads)
     cells = {}
     for bsz in (2, 8):
@@ -245,8 +264,7 @@ def cpu_baseline(hgate=False, budget_s=45.0):
     value, cores = cells[best]["clips_per_s"], threads
     saturated = None
     if not hgate:
-        left = budget_s - (time.perf_counter() - t_start)
-        saturated = cpu_baseline_saturated(c, K, phys, usable, limit_s=max(10.0, min(25.0, left + 8.0)))
+        saturated = sat_cell.run(limit_s=40.0)
         if saturated and saturated.get("clips_per_s", 0.0) > value:
             value, cores, best = saturated["clips_per_s"], saturated["processes"] * saturated["threads_per_process"], "host_saturated_eval_B2"
     return {"value": value, "unit": "clips/s", "cores": cores, "kind": "port",

@@ -78,11 +78,13 @@ class _FusedBlock(torch.autograd.Function):
         cw = (lambda w: w) if dt == torch.float32 else (lambda w: w.to(dt))
         fuse = HF.can_fuse_row_stats(x)           # the producing epilogue delivers the LayerNorm statistics
         if deterministic and fuse:
-            # the epilogue adds one partial (sum, sum of squares) per 256-wide column tile -- and per frame of a merged
-            # row -- with fp32 atomics: two addends onto zero commute exactly, more do not.  Bit-reproducible eval
-            # takes the separate statistics pass (and the merge pass) wherever a row would collect more than two.
-            tiles = -(-d // 256)
-            if tiles > 2:
+            # Bit-reproducible forward.  The 256-wide-tile kernels (N % 256 == 0) combine a tile's partial row sums in a
+            # fixed order and add ONE (sum, sum of squares) per column tile -- and per frame of a merged row -- to the
+            # row's global slot with fp32 atomics: two addends onto zero commute exactly, more do not.  The 128-wide-tile
+            # kernels (N = 128) accumulate a tile's partials with LDS atomics in arrival order.  Eval takes the separate
+            # statistics pass (and the merge pass) wherever the epilogue's result could depend on timing.
+            tiles = d // 256
+            if d % 256 or tiles > 2:
                 fuse = False
             elif merge_out and 2 * tiles > 2:
                 merge_out = False

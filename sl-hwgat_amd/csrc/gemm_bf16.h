@@ -72,3 +72,8 @@ struct TnArgsB {
 int hwgat_launch_tn256_bf16(TnArgsB a, hipStream_t st);
 
 int hwgat_launch_nt256_bf16(const NtArgsB& a, int pro, int epi, hipStream_t st);
+
+// defined in gemm_bf16_nt8w.hip: the same tile on eight waves with LDS-DMA operand streaming and a register epilogue;
+// M % 256 == N % 256 == K % 128 == 0, no A-side prologue (PRO_NONE / PRO_LN_FOLD)
+bool hwgat_nt8w_bf16_takes(const NtArgsB& a, int pro, int epi);
+int hwgat_launch_nt8w_bf16(const NtArgsB& a, int pro, int epi, hipStream_t st);

@@ -588,7 +588,11 @@ extern "C" int hwgat_linear_nt_bf16_ex(const void* A, const void* W, const float
         const int64_t m256 = M / 256 * 256;
         NtArgsB b = a;
         b.M = m256;
-        const int rc = hwgat_launch_nt256_bf16(b, pro, epi, st);
+        // ... on the eight-wave LDS-DMA kernel (gemm_bf16_nt8w.hip) where it applies; HWGAT_NT8W=0 (lab builds) keeps
+        // the one-wave-per-SIMD kernel for A/B runs
+        static const bool no8w = [] { const char* e = lab_env("HWGAT_NT8W"); return e && e[0] == '0'; }();
+        const int rc = (!no8w && hwgat_nt8w_bf16_takes(b, pro, epi)) ? hwgat_launch_nt8w_bf16(b, pro, epi, st)
+                                                                      : hwgat_launch_nt256_bf16(b, pro, epi, st);
         if (rc || m256 == M) return rc;
         const NtArgsB t = nt_rows_b(a, m256, M - m256);   // 128 rows left: RAGGED instantiation (global row index in the dropout hash)
         switch (pro) {

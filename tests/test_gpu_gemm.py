@@ -550,3 +550,78 @@ def test_epilogue_row_statistics_on_rows_whose_mean_dwarfs_their_spread(offset, 
     assert rel_err(mean.cpu(), truth_m.cpu()) < 1e-6
     assert e_two_pass < 1e-6
     assert e_fused < 8e-7 * (1 + offset * offset)
+
+
+# ---- the eight-wave LDS-DMA bf16 NT kernel (gemm_bf16_nt8w.hip): M % 256 == N % 256 == K % 128 == 0, no A-side prologue.
+# Every output element of every epilogue it implements against fp64, at shapes that hit: a single tile (grid of one
+# block: prologue / tail waits only), one K-tile pair per tile (K = 128: every iteration switches tiles), long K
+# (12 pairs), more tiles than resident blocks (blocks stream across tile boundaries), odd tile counts.
+_NT8W_SHAPES = [(256, 256, 128), (256, 256, 512), (512, 768, 128), (256 * 3, 512, 1536), (256 * 37, 256, 256),
+                (256 * 130, 512, 128), (256 * 67, 1536, 512)]
+
+
+@pytest.mark.parametrize("epi", ["none", "bias", "drop_res", "drop_res_stats", "drop_res_merge", "mul_aux", "fold_bias",
+                                 "fold_gelu_g", "gelu_g"])
+@pytest.mark.parametrize("M,N,K", _NT8W_SHAPES)
+def test_bf16_nt8w_every_epilogue_every_element(M, N, K, epi):
+    p = 0.1
+    g = torch.Generator(device=DEV).manual_seed(M * 7 + N + K + len(epi))
+    A = torch.randn(M, K, device=DEV, generator=g).bfloat16()
+    W32 = torch.randn(N, K, device=DEV, generator=g) * 0.1
+    W = W32.bfloat16()
+    b = torch.randn(N, device=DEV, generator=g)
+    res = (torch.randn(M, N, device=DEV, generator=g) + 0.3).bfloat16()
+    aux = torch.randn(M, N, device=DEV, generator=g).bfloat16()
+    gamma, beta = 1 + 0.3 * torch.randn(K, device=DEV, generator=g), 0.3 * torch.randn(K, device=DEV, generator=g)
+    Ad, Wd = A.double(), W.double()
+    lin = Ad @ Wd.t()
+    mask = HF.dropout_mask((M, N), 4321, p, DEV).double()
+    got2 = ref2 = None
+    tol = BT
+    if epi == "none":
+        got, ref = HF.linear_nt(A, W, None, epi=HF.EPI_NONE), lin
+    elif epi == "bias":
+        got, ref = HF.linear_nt(A, W, b, epi=HF.EPI_BIAS), lin + b.double()
+    elif epi in ("drop_res", "drop_res_stats", "drop_res_merge"):
+        ref = res.double() + (lin + b.double()) * mask
+        if epi == "drop_res":
+            got = HF.linear_nt(A, W, b, epi=HF.EPI_BIAS_DROP_RES, res=res, epi_seed=4321, epi_p=p)
+        else:
+            F, Kt = 4, M // 8                               # (B = 2, F = 4, K_tok = M / 8) token grid
+            merge = (F, Kt) if epi == "drop_res_merge" else None
+            got, mean, rstd = HF.linear_nt(A, W, b, epi=HF.EPI_BIAS_DROP_RES, res=res, epi_seed=4321, epi_p=p, stats=True, merge=merge)
+            if merge:
+                ref = ref.view(2, F // 2, 2, Kt, N).transpose(2, 3).reshape(-1, 2 * N)
+                got = got.reshape(-1, 2 * N)
+            gd = got.double()                               # statistics of the stored (bf16) values
+            assert rel_err(mean.cpu(), gd.mean(-1).cpu()) < 1e-5
+            assert rel_err(rstd.cpu(), (gd.var(-1, unbiased=False) + 1e-5).rsqrt().cpu()) < 1e-5
+    elif epi == "mul_aux":
+        got, ref = HF.linear_nt(A, W, None, epi=HF.EPI_MUL_AUX, aux=aux), lin * aux.double()
+    else:
+        if epi.startswith("fold"):
+            ln = HF.ln_stats(A, gamma, beta) + (gamma, beta)
+            xn = torch.nn.functional.layer_norm(Ad, (K,), gamma.double(), beta.double())
+            pre = xn @ W32.double().t() + b.double()
+            tol = 1.5e-2                                    # the fold cancels mean * s against the product (bf16 operands)
+            if epi == "fold_bias":
+                got, ref = HF.linear_nt_ln(A, W32, b, ln), pre
+            else:
+                got, got2 = HF.linear_nt_ln(A, W32, b, ln, epi=HF.EPI_BIAS_GELU_DROP_G, epi_seed=4321, epi_p=p)
+        else:
+            pre = lin + b.double()
+            got, got2 = HF.linear_nt(A, W, b, epi=HF.EPI_BIAS_GELU_DROP_G, epi_seed=4321, epi_p=p)
+        if got2 is not None:
+            h = pre.clone().requires_grad_(True)
+            torch.nn.functional.gelu(h).sum().backward()
+            ref, ref2 = torch.nn.functional.gelu(pre) * mask, h.grad * mask
+    assert got.shape == ref.shape
+    assert bool(torch.isfinite(got.float()).all())
+    assert rel_err(got.float().cpu(), ref.cpu()) < tol
+    # tile by tile: a misplaced or stale 256 x 256 tile is a relative error of ~1.4 on that tile
+    gt, rt = got.float().reshape(-1, ref.shape[-1]), ref.reshape(-1, ref.shape[-1])
+    per_tile = ((gt.double() - rt).reshape(rt.shape[0] // 256, 256, -1).norm(dim=(1, 2)) /
+                rt.reshape(rt.shape[0] // 256, 256, -1).norm(dim=(1, 2)))
+    assert float(per_tile.max()) < 3 * tol, float(per_tile.max())
+    if ref2 is not None:
+        assert rel_err(got2.float().cpu(), ref2.cpu()) < 2 * tol
