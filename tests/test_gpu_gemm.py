@@ -620,8 +620,8 @@ def test_bf16_nt8w_every_epilogue_every_element(M, N, K, epi):
     assert rel_err(got.float().cpu(), ref.cpu()) < tol
     # tile by tile: a misplaced or stale 256 x 256 tile is a relative error of ~1.4 on that tile
     gt, rt = got.float().reshape(-1, ref.shape[-1]), ref.reshape(-1, ref.shape[-1])
-    per_tile = ((gt.double() - rt).reshape(rt.shape[0] // 256, 256, -1).norm(dim=(1, 2)) /
-                rt.reshape(rt.shape[0] // 256, 256, -1).norm(dim=(1, 2)))
+    per_tile = ((gt.double() - rt).reshape(rt.shape[0] // 128, 128, -1, 256).norm(dim=(1, 3)) /
+                rt.reshape(rt.shape[0] // 128, 128, -1, 256).norm(dim=(1, 3)))
     assert float(per_tile.max()) < 3 * tol, float(per_tile.max())
     if ref2 is not None:
         assert rel_err(got2.float().cpu(), ref2.cpu()) < 2 * tol
