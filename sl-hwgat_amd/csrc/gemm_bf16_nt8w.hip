@@ -47,8 +47,10 @@ __device__ __forceinline__ void wg_barrier() {          // raw: no implicit vmcn
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// STAT: 0 = plain epilogue, 1 = + row statistics, 2 = + row statistics and the merged store, 3 = folded LayerNorm
-template <int EPI, int STAT>
+// STAT: 0 = plain epilogue, 1 = + row statistics, 2 = + row statistics and the merged store, 3 = folded LayerNorm.
+// DBG (lab builds only, wrong results by design): 1 = no epilogue stores, 2 = no DMA waits, 3 = no DMA at all,
+// 4 = no DMA and no fragment reads -- what each part of the schedule costs (tools/nt8w_lab.py).
+template <int EPI, int STAT, int DBG = 0>
 __global__ __launch_bounds__(512, 2) void gemm_nt8w_bf16_k(NtArgsB p) {
     __shared__ __attribute__((aligned(16))) unsigned char smb[SMEM];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -95,6 +97,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8w_bf16_k(NtArgsB p) {
     auto x_row = [&](int h, int j) { return gm * 128 + h * 64 + ((wave & 3) * 2 + j) * 8; };
     auto w_row = [&](int h, int j) { return (wave >> 1) * 64 + ((wave & 1) * 2 + j) * 16 + h * 8; };
     auto stage_x = [&](int buf, int h, __amdgpu_buffer_rsrc_t rs, int kb) {
+        if constexpr (DBG >= 3) return;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int r = x_row(h, j);
@@ -102,6 +105,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8w_bf16_k(NtArgsB p) {
         }
     };
     auto stage_w = [&](int buf, int h, __amdgpu_buffer_rsrc_t rs, int kb) {
+        if constexpr (DBG >= 3) return;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int r = w_row(h, j);
@@ -126,7 +130,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8w_bf16_k(NtArgsB p) {
 
     f32x4 acc[8][4];
     bf16x8 xf[4][2], wf[4][2];
+    if constexpr (DBG >= 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) { xf[i][kc] = bf16x8{}; wf[i][kc] = bf16x8{}; }
+    }
     auto read_x = [&](int buf, int half) {
+        if constexpr (DBG >= 4) return;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -134,6 +145,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8w_bf16_k(NtArgsB p) {
                 xf[i][kc] = *reinterpret_cast<const bf16x8*>(smb + buf * BUFB + lx[kc] + (half * 4 + i) * (16 * ROWB));
     };
     auto read_w = [&](int buf, int half) {
+        if constexpr (DBG >= 4) return;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -189,7 +201,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8w_bf16_k(NtArgsB p) {
             // A stage issued in phase q is first read in phase q + 5; the wait of phase q + 3 (after that phase's own
             // issue: three younger stages = 6 DMA instructions may stay in flight) retires it, the barrier behind it makes
             // every wave's pieces visible, one whole phase before the first read.
-#define HWGAT_WAIT(NLAST) do { if (more) wait_vm<6>(); else wait_vm<NLAST>(); } while (0)
+#define HWGAT_WAIT(NLAST) do { if constexpr (DBG < 2) { if (more) wait_vm<6>(); else wait_vm<NLAST>(); } } while (0)
             // phase 1: quadrant (0,0) of K-tile A (buffer 0)
             read_x(0, 0); read_w(0, 0);
             stage_w(1, 1, wc, kb_c);
@@ -351,8 +363,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8w_bf16_k(NtArgsB p) {
                 }
                 bf16_t* dst = p.C + off;
                 if constexpr (STAT == X_STAT_MERGE) { dst = p.C + mw.off(p.N) + col; mw.next(); }
-                *reinterpret_cast<u32x4*>(dst) = out0;
-                *reinterpret_cast<u32x4*>(dst + 8) = out1;
+                if constexpr (DBG == 1) {
+                    asm volatile("" ::"v"(out0), "v"(out1));
+                } else {
+                    *reinterpret_cast<u32x4*>(dst) = out0;
+                    *reinterpret_cast<u32x4*>(dst + 8) = out1;
+                }
             }
             if constexpr (STAT == X_STAT || STAT == X_STAT_MERGE) {
                 wait_lds();
@@ -403,6 +419,17 @@ int hwgat_launch_nt8w_bf16(const NtArgsB& a, int pro, int epi, hipStream_t st) {
         if (epi == EPI_BIAS_GELU_DROP) return go<EPI_BIAS_GELU_DROP, X_LNFOLD>(a, grid, st);
         return go<EPI_BIAS_GELU_DROP_G, X_LNFOLD>(a, grid, st);
     }
+#ifdef HWGAT_LAB
+    if (epi == EPI_NONE) {
+        const char* e = lab_env("HWGAT_NT8W_DBG");
+        const int dbg = e ? atoi(e) : 0;
+        auto run = [&](auto tag) { gemm_nt8w_bf16_k<EPI_NONE, X_NONE, decltype(tag)::value><<<grid, 512, 0, st>>>(a); };
+        if (dbg == 1) { run(std::integral_constant<int, 1>{}); HWGAT_LAUNCH_CHECK(); }
+        if (dbg == 2) { run(std::integral_constant<int, 2>{}); HWGAT_LAUNCH_CHECK(); }
+        if (dbg == 3) { run(std::integral_constant<int, 3>{}); HWGAT_LAUNCH_CHECK(); }
+        if (dbg == 4) { run(std::integral_constant<int, 4>{}); HWGAT_LAUNCH_CHECK(); }
+    }
+#endif
     switch (epi) {
         case EPI_NONE: return go<EPI_NONE, X_NONE>(a, grid, st);
         case EPI_BIAS: return go<EPI_BIAS, X_NONE>(a, grid, st);

@@ -600,7 +600,10 @@ def test_bf16_nt8w_every_epilogue_every_element(M, N, K, epi):
         got, ref = HF.linear_nt(A, W, None, epi=HF.EPI_MUL_AUX, aux=aux), lin * aux.double()
     else:
         if epi.startswith("fold"):
-            ln = HF.ln_stats(A, gamma, beta) + (gamma, beta)
+            if K in (128, 256, 512, 1024):
+                ln = HF.ln_stats(A, gamma, beta) + (gamma, beta)
+            else:                                           # hwgat_ln_fwd covers the model's LayerNorm widths only
+                ln = (Ad.mean(-1).float(), (Ad.var(-1, unbiased=False) + 1e-5).rsqrt().float(), gamma, beta)
             xn = torch.nn.functional.layer_norm(Ad, (K,), gamma.double(), beta.double())
             pre = xn @ W32.double().t() + b.double()
             tol = 1.5e-2                                    # the fold cancels mean * s against the product (bf16 operands)
