@@ -13,13 +13,13 @@
 //     its LDS fragment reads and its share of the DMA for a later K-tile;
 //   * the product is formed TRANSPOSED (MFMA A operand = weight rows, B operand = activation rows), and the weight rows
 //     are dealt to the four 16-row MFMA tiles of a wave so that a lane ends up with 16 CONSECUTIVE output columns of one
-//     output row: the epilogue runs straight from the accumulators -- no LDS staging, 2 x 16-byte stores per row and
-//     lane, 128-byte row segments per wave -- with two waves per SIMD to share the vector pipe.
+//     output row; the epilogue runs with two waves per SIMD sharing the vector pipe.
 //
+// (the epilogue turns each 16-row piece through a wave-private LDS strip so that its global accesses are whole lines)
 // LDS image of one K-tile (BK = 64): activations [256 rows][128 B] | weights [256 rows][128 B], 16-byte chunks of a row
 // XOR-swizzled so that every ds_read_b128 fragment read is bank-conflict free; the DMA writes LDS linearly (wave base +
 // lane x 16 B), so the swizzle is applied to the per-lane SOURCE address (8 rows x 128 B = whole lines per piece).  Two
-// K-tile buffers (128 KiB) + 8 KiB of row-statistics scratch.
+// K-tile buffers (128 KiB) + 32 KiB of epilogue strips.
 //
 // Needs M % 256 == N % 256 == K % 128 == 0, no A-side prologue (PRO_NONE or the folded LayerNorm); everything else stays
 // on gemm_nt256_bf16_k / gemm_nt_bf16_k (hwgat_linear_nt_bf16 decides).
@@ -34,8 +34,8 @@ constexpr int BT = 256, BK = 64;
 constexpr int ROWB = 2 * BK;                  // bytes of one LDS row (one K-tile of one matrix row)
 constexpr int OPB = BT * ROWB;                // one operand tile: 32 KiB
 constexpr int BUFB = 2 * OPB;                 // activations | weights of one K-tile: 64 KiB
-constexpr int STAT_OFF = 2 * BUFB;            // row statistics: [4 column quarters][256 rows] x (sum, sum of squares)
-constexpr int SMEM = STAT_OFF + 4 * BT * 2 * 4;
+constexpr int STRIP_OFF = 2 * BUFB;           // epilogue: one 16-row x 64-fp32 strip per wave (the row statistics alias them)
+constexpr int SMEM = STRIP_OFF + 8 * 16 * 256;   // 160 KiB, all of the CU's LDS
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
@@ -242,19 +242,25 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8w_bf16_k(NtArgsB p) {
         if (gm == 0) wg_barrier();                          // waves 0-3 wait for the partner's last cluster: both groups
                                                             // run the epilogue together (two waves per SIMD share the vector pipe)
 
-        // ---- epilogue, straight from the accumulators.  acc[mt][t][r]: row m0 + gm*128 + mt*16 + fr,
-        // column n0 + wn*64 + fq*16 + t*4 + r  -> 16 consecutive columns (32 bytes of bf16) per lane and row.
+        // ---- epilogue.  acc[mt][t][r] is row m0 + gm*128 + mt*16 + fr, column n0 + wn*64 + fq*16 + t*4 + r: the four lanes
+        // that hold one output row are 16 lanes apart, and a store / load instruction whose neighbouring lanes touch
+        // different rows is issued as 64 separate 16-byte requests (measured: 6.7 us of store tail per tile, a third of a
+        // K = 512 tile).  So each 16-row piece first turns through a WAVE-PRIVATE 4 KiB LDS strip (16 rows x 64 fp32,
+        // 16-byte chunks XOR-swizzled by the row: conflict-free both ways, no barrier -- a wave's DS operations execute in
+        // order), after which lane l owns row (l>>3) of 8-row pass ps, columns (l&7)*8 .. +7: eight neighbouring lanes
+        // = one whole 128-byte line of C (and of the residual / auxiliary operand), 8 lines per instruction.
         {
             const uint32_t epi_th = drop_thresh(p.epi_p);
             const float epi_sc = 1.0f / (1.0f - p.epi_p);
-            const int col = n0 + wn * 64 + fq * 16;
-            float cb[16];                                   // bias, or c_n of the folded LayerNorm
-            float cs[16];                                   // s_n of the folded LayerNorm
+            const int er = lane >> 3, ec = (lane & 7) * 8;
+            const int col = n0 + wn * 64 + ec;
+            unsigned char* strip = smb + STRIP_OFF + wave * (16 * 256);
+            float cb[8], cs[8];                             // bias (or c_n of the folded LayerNorm); s_n of the fold
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { cb[e] = 0.f; cs[e] = 0.f; }
+            for (int e = 0; e < 8; ++e) { cb[e] = 0.f; cs[e] = 0.f; }
             if constexpr (STAT == X_LNFOLD) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int q = 0; q < 2; ++q) {
                     const f32x4 s4 = *reinterpret_cast<const f32x4*>(p.gamma + col + 4 * q);
                     const f32x4 c4 = *reinterpret_cast<const f32x4*>(p.beta + col + 4 * q);
 #pragma unroll
@@ -263,114 +269,118 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8w_bf16_k(NtArgsB p) {
             } else if constexpr (epi_has_bias(EPI)) {
                 if (p.bias) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
+                    for (int q = 0; q < 2; ++q) {
                         const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + col + 4 * q);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) cb[4 * q + e] = b4[e];
                     }
                 }
             }
-            float* rowstat = reinterpret_cast<float*>(smb + STAT_OFF);
+            float st1[16], st2[16];                         // row statistics of this lane's 16 (piece, pass) rows
             MergeWalk mw;
-            if constexpr (STAT == X_STAT_MERGE) mw.start(m0 + gm * 128 + fr, p.mg_F, p.mg_K, 16);
+            if constexpr (STAT == X_STAT_MERGE) mw.start(m0 + gm * 128 + er, p.mg_F, p.mg_K, 8);
 #pragma unroll
             for (int mt = 0; mt < 8; ++mt) {
-                const int64_t row = m0 + gm * 128 + mt * 16 + fr;
-                const int64_t off = row * p.N + col;
-                u32x4 ex0, ex1;                             // residual / auxiliary operand of the lane's 16 columns
+                // the residual / auxiliary operand of both passes is requested before the piece is parked
+                u32x4 ex[2];
                 if constexpr (epi_reads_extra(EPI)) {
-                    const bf16_t* src = (EPI == EPI_BIAS_DROP_RES ? p.res : p.aux) + off;
-                    ex0 = *reinterpret_cast<const u32x4*>(src);
-                    ex1 = *reinterpret_cast<const u32x4*>(src + 8);
+                    const bf16_t* src = (EPI == EPI_BIAS_DROP_RES ? p.res : p.aux) + (m0 + gm * 128 + mt * 16 + er) * p.N + col;
+                    ex[0] = *reinterpret_cast<const u32x4*>(src);
+                    ex[1] = *reinterpret_cast<const u32x4*>(src + 8 * (int64_t)p.N);
                 }
-                float o[16];
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt)
+                    *reinterpret_cast<f32x4*>(strip + fr * 256 + (((fq * 4 + tt) ^ fr) << 4)) = acc[mt][tt];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // other lanes' writes, this lane's reads: keep the order
+                __builtin_amdgcn_wave_barrier();
+                f32x4 pv[2][2];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[4 * tt + r] = acc[mt][tt][r];
-                if constexpr (STAT == X_LNFOLD) {
-                    const float rr = p.rstd[row], tm = p.mean[row] * rr;
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) o[e] = o[e] * rr + (cb[e] - cs[e] * tm);
-                } else if constexpr (epi_has_bias(EPI)) {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) o[e] += cb[e];
+                for (int ps = 0; ps < 2; ++ps) {
+                    const int R = ps * 8 + er;
+                    pv[ps][0] = *reinterpret_cast<const f32x4*>(strip + R * 256 + (((ec >> 2) ^ R) << 4));
+                    pv[ps][1] = *reinterpret_cast<const f32x4*>(strip + R * 256 + ((((ec >> 2) + 1) ^ R) << 4));
                 }
-                float dk[16];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // ... and the next piece's writes behind these reads
+                __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int e = 0; e < 16; ++e) dk[e] = 1.f;
-                if constexpr (epi_drops(EPI)) {
-                    if (epi_th) {
+                for (int ps = 0; ps < 2; ++ps) {
+                    const int R = ps * 8 + er;
+                    const int64_t row = m0 + gm * 128 + mt * 16 + R;
+                    const int64_t off = row * p.N + col;
+                    const f32x4 v0 = pv[ps][0], v1 = pv[ps][1];
+                    float o[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    if constexpr (STAT == X_LNFOLD) {
+                        const float rr = p.rstd[row], tm = p.mean[row] * rr;
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const f32x4 k4 = drop_keep4(p.epi_seed, (uint64_t)off + 4 * q, epi_th, epi_sc);
+                        for (int e = 0; e < 8; ++e) o[e] = o[e] * rr + (cb[e] - cs[e] * tm);
+                    } else if constexpr (epi_has_bias(EPI)) {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) dk[4 * q + e] = k4[e];
+                        for (int e = 0; e < 8; ++e) o[e] += cb[e];
+                    }
+                    float dk[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+                    if constexpr (epi_drops(EPI)) {
+                        if (epi_th) {
+                            const f32x4 k0 = drop_keep4(p.epi_seed, (uint64_t)off, epi_th, epi_sc), k1 = drop_keep4(p.epi_seed, (uint64_t)off + 4, epi_th, epi_sc);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { dk[e] = k0[e]; dk[4 + e] = k1[e]; }
                         }
                     }
-                }
-                float g[16];
-                if constexpr (EPI == EPI_BIAS_DROP_RES) {
-                    float r0[8], r1[8];
-                    unpack8(ex0, r0); unpack8(ex1, r1);
+                    if constexpr (EPI == EPI_BIAS_DROP_RES) {
+                        float rs[8];
+                        unpack8(ex[ps], rs);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { o[e] = r0[e] + o[e] * dk[e]; o[8 + e] = r1[e] + o[8 + e] * dk[8 + e]; }
-                } else if constexpr (EPI == EPI_BIAS_GELU_DROP) {
-                    float h0[8], h1[8], q0[8], q1[8];
+                        for (int e = 0; e < 8; ++e) o[e] = rs[e] + o[e] * dk[e];
+                    } else if constexpr (EPI == EPI_BIAS_GELU_DROP) {
+                        const u32x4 pre = pack8(o);
+                        *reinterpret_cast<u32x4*>(p.C2 + off) = pre;
+                        float h[8];
+                        unpack8(pre, h);                    // gelu on the bf16-rounded pre-activation that backward will see
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { q0[e] = o[e]; q1[e] = o[8 + e]; }
-                    const u32x4 pre0 = pack8(q0), pre1 = pack8(q1);
-                    *reinterpret_cast<u32x4*>(p.C2 + off) = pre0;
-                    *reinterpret_cast<u32x4*>(p.C2 + off + 8) = pre1;
-                    unpack8(pre0, h0); unpack8(pre1, h1);   // gelu on the bf16-rounded pre-activation that backward will see
+                        for (int e = 0; e < 8; ++e) o[e] = gelu_f(h[e]) * dk[e];
+                    } else if constexpr (EPI == EPI_BIAS_GELU_DROP_G) {
+                        float g8[8];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { o[e] = gelu_f(h0[e]) * dk[e]; o[8 + e] = gelu_f(h1[e]) * dk[8 + e]; }
-                } else if constexpr (EPI == EPI_BIAS_GELU_DROP_G) {
+                        for (int e = 0; e < 8; ++e) gelu_fwd_grad(o[e], dk[e], o[e], g8[e]);
+                        *reinterpret_cast<u32x4*>(p.C2 + off) = pack8(g8);
+                    } else if constexpr (EPI == EPI_MUL_AUX) {
+                        float h[8];
+                        unpack8(ex[ps], h);
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) gelu_fwd_grad(o[e], dk[e], o[e], g[e]);
-                    float q0[8], q1[8];
+                        for (int e = 0; e < 8; ++e) o[e] *= h[e];
+                    } else if constexpr (EPI == EPI_GELU_BWD) {
+                        float h[8];
+                        unpack8(ex[ps], h);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { q0[e] = g[e]; q1[e] = g[8 + e]; }
-                    *reinterpret_cast<u32x4*>(p.C2 + off) = pack8(q0);
-                    *reinterpret_cast<u32x4*>(p.C2 + off + 8) = pack8(q1);
-                } else if constexpr (EPI == EPI_MUL_AUX) {
-                    float h0[8], h1[8];
-                    unpack8(ex0, h0); unpack8(ex1, h1);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) { o[e] *= h0[e]; o[8 + e] *= h1[e]; }
-                } else if constexpr (EPI == EPI_GELU_BWD) {
-                    float h0[8], h1[8];
-                    unpack8(ex0, h0); unpack8(ex1, h1);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) { o[e] = o[e] * dk[e] * gelu_grad(h0[e]); o[8 + e] = o[8 + e] * dk[8 + e] * gelu_grad(h1[e]); }
-                }
-                float q0[8], q1[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { q0[e] = o[e]; q1[e] = o[8 + e]; }
-                const u32x4 out0 = pack8(q0), out1 = pack8(q1);
-                if constexpr (STAT == X_STAT || STAT == X_STAT_MERGE) {   // statistics of what the next LayerNorm reads: the bf16 values
-                    float v0[8], v1[8];
-                    unpack8(out0, v0); unpack8(out1, v1);
-                    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) { s1 += v0[e] + v1[e]; s2 += v0[e] * v0[e] + v1[e] * v1[e]; }
-                    s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
-                    s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
-                    if (fq == 0) {
-                        f32x2 st = {s1, s2};
-                        *reinterpret_cast<f32x2*>(rowstat + (wn * BT + gm * 128 + mt * 16 + fr) * 2) = st;
+                        for (int e = 0; e < 8; ++e) o[e] = o[e] * dk[e] * gelu_grad(h[e]);
                     }
-                }
-                bf16_t* dst = p.C + off;
-                if constexpr (STAT == X_STAT_MERGE) { dst = p.C + mw.off(p.N) + col; mw.next(); }
-                if constexpr (DBG == 1) {
-                    asm volatile("" ::"v"(out0), "v"(out1));
-                } else {
-                    *reinterpret_cast<u32x4*>(dst) = out0;
-                    *reinterpret_cast<u32x4*>(dst + 8) = out1;
+                    const u32x4 outv = pack8(o);
+                    if constexpr (STAT == X_STAT || STAT == X_STAT_MERGE) {   // statistics of what the next LayerNorm reads: the bf16 values
+                        float q[8];
+                        unpack8(outv, q);
+                        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { s1 += q[e]; s2 += q[e] * q[e]; }
+                        st1[mt * 2 + ps] = group_sum<8>(s1);
+                        st2[mt * 2 + ps] = group_sum<8>(s2);
+                    }
+                    bf16_t* dst = p.C + off;
+                    if constexpr (STAT == X_STAT_MERGE) { dst = p.C + mw.off(p.N) + col; mw.next(); }
+                    if constexpr (DBG == 1) asm volatile("" ::"v"(outv));
+                    else *reinterpret_cast<u32x4*>(dst) = outv;
                 }
             }
             if constexpr (STAT == X_STAT || STAT == X_STAT_MERGE) {
+                // [4 column quarters][256 rows] x (sum, sum of squares) in the strip area, once every wave is done with its strip
+                float* rowstat = reinterpret_cast<float*>(smb + STRIP_OFF);
+                wait_lds();
+                wg_barrier();
+                if ((lane & 7) == 0) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        f32x2 st = {st1[q], st2[q]};
+                        *reinterpret_cast<f32x2*>(rowstat + (wn * BT + gm * 128 + (q >> 1) * 16 + (q & 1) * 8 + er) * 2) = st;
+                    }
+                }
                 wait_lds();
                 wg_barrier();
                 if (tid < BT) {                             // fixed order over the four column quarters, one atomic per row and tile
@@ -381,7 +391,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8w_bf16_k(NtArgsB p) {
                     atomicAdd(p.stat_sum + mr, a1);
                     atomicAdd(p.stat_sq + mr, a2);
                 }
-                wg_barrier();                               // the scratch is rewritten by the next tile's epilogue
+                wait_lds();
+                wg_barrier();                               // the strips are rewritten by the next tile's epilogue
             }
         }
         t = tn;
