@@ -202,42 +202,41 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8w_bf16_k(NtArgsB p) {
             // issue: three younger stages = 6 DMA instructions may stay in flight) retires it, the barrier behind it makes
             // every wave's pieces visible, one whole phase before the first read.
 #define HWGAT_WAIT(NLAST) do { if constexpr (DBG < 2) { if (more) wait_vm<6>(); else wait_vm<NLAST>(); } } while (0)
-            // The fragment reads of phase q + 1 are issued at the END of phase q's MFMA slot (into registers whose last
-            // readers, this slot's MFMAs, have issued): the LDS serves them while the partner wave runs its cluster, and
-            // the slot between the barriers that carries the DMA issue stays short.  Only a tile's very first phase
-            // reads in its own slot.
-#define HWGAT_MFMA(MH, TH) do { wg_barrier(); wait_lds(); __builtin_amdgcn_sched_barrier(0); mfma16(MH, TH); __builtin_amdgcn_sched_barrier(0); } while (0)
             // phase 1: quadrant (0,0) of K-tile A (buffer 0)
-            if (it == 0) { read_x(0, 0); read_w(0, 0); }
+            read_x(0, 0); read_w(0, 0);
             stage_w(1, 1, wc, kb_c);
             HWGAT_WAIT(6);
-            HWGAT_MFMA(0, 0); read_w(0, 1); wg_barrier();
+            wg_barrier(); wait_lds(); __builtin_amdgcn_sched_barrier(0); mfma16(0, 0); wg_barrier();
             // phase 2: quadrant (0,1)
+            read_w(0, 1);
             stage_x(1, 1, xc, kb_c);
             HWGAT_WAIT(6);
-            HWGAT_MFMA(0, 1); read_x(0, 1); wg_barrier();
+            wg_barrier(); wait_lds(); __builtin_amdgcn_sched_barrier(0); mfma16(0, 1); wg_barrier();
             // phase 3: quadrant (1,1)
+            read_x(0, 1);
             if (more) stage_x(0, 0, xn, kb_n);
             HWGAT_WAIT(4);
-            HWGAT_MFMA(1, 1); wg_barrier();
+            wg_barrier(); wait_lds(); __builtin_amdgcn_sched_barrier(0); mfma16(1, 1); wg_barrier();
             // phase 4: quadrant (1,0) -- the column-half-0 weight fragments are still in registers
             if (more) stage_w(0, 0, wnx, kb_n);
             HWGAT_WAIT(2);
-            HWGAT_MFMA(1, 0); read_x(1, 0); read_w(1, 0); wg_barrier();
+            wg_barrier(); __builtin_amdgcn_sched_barrier(0); mfma16(1, 0); wg_barrier();
             // phases 5-8: the same on K-tile B (buffer 1)
+            read_x(1, 0); read_w(1, 0);
             if (more) stage_w(0, 1, wnx, kb_n);
             HWGAT_WAIT(0);
-            HWGAT_MFMA(0, 0); read_w(1, 1); wg_barrier();
+            wg_barrier(); wait_lds(); __builtin_amdgcn_sched_barrier(0); mfma16(0, 0); wg_barrier();
+            read_w(1, 1);
             if (more) stage_x(0, 1, xn, kb_n);
             HWGAT_WAIT(0);
-            HWGAT_MFMA(0, 1); read_x(1, 1); wg_barrier();
+            wg_barrier(); wait_lds(); __builtin_amdgcn_sched_barrier(0); mfma16(0, 1); wg_barrier();
+            read_x(1, 1);
             if (more) stage_x(1, 0, xn, kb_n + 2 * BK);
             HWGAT_WAIT(0);
-            HWGAT_MFMA(1, 1); wg_barrier();
+            wg_barrier(); wait_lds(); __builtin_amdgcn_sched_barrier(0); mfma16(1, 1); wg_barrier();
             if (more) stage_w(1, 0, wnx, kb_n + 2 * BK);
             HWGAT_WAIT(0);
-            HWGAT_MFMA(1, 0); if (!last_it) { read_x(0, 0); read_w(0, 0); } wg_barrier();
-#undef HWGAT_MFMA
+            wg_barrier(); __builtin_amdgcn_sched_barrier(0); mfma16(1, 0); wg_barrier();
 #undef HWGAT_WAIT
         }
         if (gm == 0) wg_barrier();                          // waves 0-3 wait for the partner's last cluster: both groups
