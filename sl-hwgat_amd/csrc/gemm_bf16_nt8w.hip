@@ -164,6 +164,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8w_bf16_k(NtArgsB p) {
         __builtin_amdgcn_s_setprio(0);
     };
 
+    // DBG 5 (lab): s_memtime stamps of waves 0 and 4 into C2 (uint64 [block][tile slot < 8][wave half][6])
+    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(p.C2);
+    int stamp_slot = 0;
+    auto stamp = [&](int which) {
+        if constexpr (DBG == 5) {
+            if ((wave & 3) == 0 && lane == 0 && stamp_slot < 8)
+                stamps[((blockIdx.x * 8 + stamp_slot) * 2 + gm) * 6 + which] = __builtin_amdgcn_s_memtime();
+        }
+    };
     int t = blockIdx.x;
     if (t >= n_tiles) return;
     int64_t m0; int n0;
@@ -181,7 +190,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8w_bf16_k(NtArgsB p) {
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        stamp(0);
         if (gm == 1) wg_barrier();                          // waves 4-7 run one barrier behind waves 0-3
+        stamp(1);
 
         const int tn = t + gridDim.x;
         int64_t mn = m0; int nn = n0;
@@ -239,6 +250,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8w_bf16_k(NtArgsB p) {
             wg_barrier(); __builtin_amdgcn_sched_barrier(0); mfma16(1, 0); wg_barrier();
 #undef HWGAT_WAIT
         }
+        stamp(2);
         if (gm == 0) wg_barrier();                          // waves 0-3 wait for the partner's last cluster: both groups
                                                             // run the epilogue together (two waves per SIMD share the vector pipe)
 
@@ -276,6 +288,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8w_bf16_k(NtArgsB p) {
                     }
                 }
             }
+            stamp(3);
             float st1[16], st2[16];                         // row statistics of this lane's 16 (piece, pass) rows
             MergeWalk mw;
             if constexpr (STAT == X_STAT_MERGE) mw.start(m0 + gm * 128 + er, p.mg_F, p.mg_K, 8);
@@ -395,6 +408,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8w_bf16_k(NtArgsB p) {
                 wg_barrier();                               // the strips are rewritten by the next tile's epilogue
             }
         }
+        stamp(4);
+        ++stamp_slot;
         t = tn;
         if (t >= n_tiles) break;
         m0 = mn; n0 = nn; xc = xn; wc = wnx;
@@ -439,6 +454,7 @@ int hwgat_launch_nt8w_bf16(const NtArgsB& a, int pro, int epi, hipStream_t st) {
         if (dbg == 2) { run(std::integral_constant<int, 2>{}); HWGAT_LAUNCH_CHECK(); }
         if (dbg == 3) { run(std::integral_constant<int, 3>{}); HWGAT_LAUNCH_CHECK(); }
         if (dbg == 4) { run(std::integral_constant<int, 4>{}); HWGAT_LAUNCH_CHECK(); }
+        if (dbg == 5 && a.C2) { run(std::integral_constant<int, 5>{}); HWGAT_LAUNCH_CHECK(); }
     }
 #endif
     switch (epi) {
