@@ -93,6 +93,13 @@ int hwgat_ln_bwd_masked(const void* dy, const void* x, const float* mean, const 
                         int64_t N, int d, int dtype, void* dx_masked, uint32_t mask_seed, float mask_p,
                         void* stream);
 
+/* The same once more, and xn = LN(x) = xhat * gamma + beta written to `xn` (N, d) `dtype`: the layer input of the Linear
+ * that follows this LayerNorm (HWGATE.py:203 -> :86, :219 -> :131), for that Linear's weight-gradient launch
+ * (hwgat_linear_tn_*), which then needs no LayerNorm in its loaders.  dres required; dx_masked may be NULL. */
+int hwgat_ln_bwd_xn(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                    const float* beta, const void* dres, void* dx, float* dgamma, float* dbeta, int64_t N, int d,
+                    int dtype, void* dx_masked, uint32_t mask_seed, float mask_p, void* xn, void* stream);
+
 /* ---- a-4/a-5/a-6/a-10: fused window attention (MSA.forward, HWGATE.py:89-114)
  * over the body-part joint graph, with partition/roll/reverse as index math.
  *   qkv      (B, F, K, 3, nH, hd) `dtype` -- the qkv Linear output in natural

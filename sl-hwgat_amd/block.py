@@ -164,29 +164,47 @@ class _FusedBlock(torch.autograd.Function):
             dwq.run(lambda: HF.linear_tn(dout, u, dw2, db2, pro_seed=seeds[2], pro_p=p))
             d_h1 = HF.linear_nt(dout, HF.transpose(w2, dt), None, pro=HF.PRO_DROP, pro_seed=seeds[2], pro_p=p,
                                 epi=HF.EPI_MUL_AUX, aux=h1)
-        dwq.run(lambda: HF.linear_tn(d_h1, y, dw1, db1, ln=(m2, r2, n2w, n2b)))
+        xn_path = HF.dw_wants_xn(x)               # LN(x) written by the LayerNorm backward for the dW launches (bf16, d % 256 == 0)
+        if not xn_path:
+            dwq.run(lambda: HF.linear_tn(d_h1, y, dw1, db1, ln=(m2, r2, n2w, n2b)))
         d_z = HF.linear_nt(d_h1, HF.transpose(w1, dt), None, epi=HF.EPI_NONE)
         # ---- attention branch: y = x + drop1(o Wp^T + bp)
         if p > 0.0 and HF.MASK_ONCE >= 1 and d >= HF.MASK_ONCE_MIN_D:
-            d_y, d_ym = HF.ln_backward(d_z, y, m2, r2, n2w, dout, dn2w, dn2b, mask=(seeds[0], p))   # + shortcut; and dropmask1 * d_y
+            if xn_path:
+                d_y, d_ym, yn = HF.ln_backward(d_z, y, m2, r2, n2w, dout, dn2w, dn2b, mask=(seeds[0], p), beta=n2b)
+                dwq.run(lambda: HF.linear_tn(d_h1, yn, dw1, db1))
+            else:
+                d_y, d_ym = HF.ln_backward(d_z, y, m2, r2, n2w, dout, dn2w, dn2b, mask=(seeds[0], p))   # + shortcut; and dropmask1 * d_y
             dwq.run(lambda: HF.linear_tn(d_ym, o, dwp, dbp))
             d_o = HF.linear_nt(d_ym, HF.transpose(wp, dt), None, epi=HF.EPI_NONE, out=d_z)
         else:
-            d_y = HF.ln_backward(d_z, y, m2, r2, n2w, dout, dn2w, dn2b)          # + shortcut gradient
+            if xn_path:
+                d_y, yn = HF.ln_backward(d_z, y, m2, r2, n2w, dout, dn2w, dn2b, beta=n2b)
+                dwq.run(lambda: HF.linear_tn(d_h1, yn, dw1, db1))
+            else:
+                d_y = HF.ln_backward(d_z, y, m2, r2, n2w, dout, dn2w, dn2b)          # + shortcut gradient
             dwq.run(lambda: HF.linear_tn(d_y, o, dwp, dbp, pro_seed=seeds[0], pro_p=p))
             d_o = HF.linear_nt(d_y, HF.transpose(wp, dt), None, pro=HF.PRO_DROP, pro_seed=seeds[0], pro_p=p,
                                epi=HF.EPI_NONE, out=d_z)
         dqkv = torch.empty_like(qkv)
         HF.attn_bwd(kind, qkv, d_o, dqkv, bits, thr, n_heads, shifted)
-        dwq.run(lambda: HF.linear_tn(dqkv, x, dwqkv, dbqkv, ln=(m1, r1, n1w, n1b)))
+        if not xn_path:
+            dwq.run(lambda: HF.linear_tn(dqkv, x, dwqkv, dbqkv, ln=(m1, r1, n1w, n1b)))
         d_xn = HF.linear_nt(dqkv, HF.transpose(wqkv, dt), None, epi=HF.EPI_NONE, out=d_o)
         # (the first block's input comes from the parameter-free embedding: its dx is still produced because
         # dgamma / dbeta of norm1 fall out of the same LayerNorm-backward pass)
         dxm = None
         if ctx.send_up:           # the block that produced x gets dropmask3(its seed) * dx through the carrier's gradient
-            dx, dxm = HF.ln_backward(d_xn, x, m1, r1, n1w, d_y, dn1w, dn1b, mask=up)
+            if xn_path:
+                dx, dxm, xn = HF.ln_backward(d_xn, x, m1, r1, n1w, d_y, dn1w, dn1b, mask=up, beta=n1b)
+            else:
+                dx, dxm = HF.ln_backward(d_xn, x, m1, r1, n1w, d_y, dn1w, dn1b, mask=up)
+        elif xn_path:
+            dx, xn = HF.ln_backward(d_xn, x, m1, r1, n1w, d_y, dn1w, dn1b, beta=n1b)
         else:
             dx = HF.ln_backward(d_xn, x, m1, r1, n1w, d_y, dn1w, dn1b)
+        if xn_path:
+            dwq.run(lambda: HF.linear_tn(dqkv, xn, dwqkv, dbqkv))
         if dxm is not None:
             book.register(dx, dxm)
         dwq.join()        # every temporary above stays referenced until here, so the allocator cannot recycle it early

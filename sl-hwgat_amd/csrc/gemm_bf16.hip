@@ -654,6 +654,13 @@ extern "C" int hwgat_linear_tn_bf16(const void* A, const void* B, float* dW, flo
     // ... where its tiles fill the 256 CUs in whole rounds of equal blocks (tile count a divisor of 256: 1, 2, 4, 8 ...);
     // 3 or 12 tiles (the qkv weight) need three rounds of short M slices and lose to the 128x128 kernel:
     // stage 2 dWqkv 492 vs 454 us, stage 1 349 vs 272 (same box, tools/tn_lab.py)
+    // plain operands, whole 256x256 tiles: the eight-wave LDS-DMA kernel (gemm_bf16_tn8w.hip); HWGAT_TN8W=0 (lab builds)
+    // keeps the kernels below for A/B runs
+    static const bool no8w = [] { const char* e = lab_env("HWGAT_TN8W"); return e && e[0] == '0'; }();
+    if (!no8w && hwgat_tn8w_bf16_takes(M, N, K, pro_p, mean)) {
+        TnArgsB a{(const bf16_t*)A, (const bf16_t*)B, dW, db, nullptr, nullptr, nullptr, nullptr, M, N, K, 1, M, pro_seed, pro_p, 0};
+        return hwgat_launch_tn8w_bf16(a, (hipStream_t)stream);
+    }
     const int t256 = (N / 256) * (K / 256);
     if (!tn_old && N % 256 == 0 && K % 256 == 0 && M % 32 == 0 && 256 % t256 == 0 && !(pro_p > 0.f && mean)) {
         TnArgsB a{(const bf16_t*)A, (const bf16_t*)B, dW, db, mean, rstd, gamma, beta, M, N, K, 1, M, pro_seed, pro_p, 0};

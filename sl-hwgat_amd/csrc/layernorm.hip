@@ -92,20 +92,26 @@ __global__ __launch_bounds__(256) void ln_fwd_k(const T* __restrict__ x, const f
 // its dropout (dX and dW of the linear whose output was dropped).  The hash is evaluated once here, in an HBM-bound
 // kernel whose vector units idle, instead of in every tile of the two GEMM loaders that consume the masked gradient
 // (8 evaluations per element at stage 2, none of them hidden behind the MFMAs).
-template <typename T, int D, bool RES, bool MASK>
+// XN: also write LN(x) = xhat * gamma + beta (the layer input of the Linear behind this LayerNorm) for that Linear's
+// weight-gradient launch, which then takes both operands plain (LDS-DMA, gemm_bf16_tn8w.hip) instead of normalising x in
+// its loaders: xhat is in registers here anyway, the pass is HBM-bound with idle vector units.
+template <typename T, int D, bool RES, bool MASK, bool XN = false>
 __global__ __launch_bounds__(256) void ln_bwd_k(const T* __restrict__ dy, const T* __restrict__ x,
                                                 const float* __restrict__ mean_i,
                                                 const float* __restrict__ rstd_i,
                                                 const float* __restrict__ gamma, const T* __restrict__ dres,
                                                 T* __restrict__ dx, float* __restrict__ dgamma,
                                                 float* __restrict__ dbeta, int64_t N, T* __restrict__ dxm,
-                                                uint32_t mseed, float mp) {
+                                                uint32_t mseed, float mp, const float* __restrict__ beta = nullptr,
+                                                T* __restrict__ xn = nullptr) {
     using M = RowMap<D>;
     __shared__ float red[2][4][D];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int sub = lane % M::LPR, rsub = lane / M::LPR;
     float g[M::CPL][4], dg[M::CPL][4], db[M::CPL][4];
     load_vec<D>(gamma, sub, g);
+    float bt[M::CPL][4];
+    if constexpr (XN) load_vec<D>(beta, sub, bt);
 #pragma unroll
     for (int c = 0; c < M::CPL; ++c)
 #pragma unroll
@@ -135,6 +141,14 @@ __global__ __launch_bounds__(256) void ln_bwd_k(const T* __restrict__ dy, const 
             }
         s1 = wave_sum<M::LPR>(s1) * (1.0f / D);
         s2 = wave_sum<M::LPR>(s2) * (1.0f / D);
+        if constexpr (XN) {
+            float nv[M::CPL][4];
+#pragma unroll
+            for (int c = 0; c < M::CPL; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) nv[c][e] = xv[c][e] * g[c][e] + bt[c][e];
+            store_row<T, D>(xn + r * D, sub, nv);
+        }
         if constexpr (RES) {
             float rv[M::CPL][4];
             load_row<T, D>(dres + r * D, sub, rv);
@@ -317,14 +331,14 @@ int ln_fwd_t(const void* x, const float* gm, const float* bt, void* y, float* me
 #undef GO
     HWGAT_LAUNCH_CHECK();
 }
-template <typename T, bool RES, bool MASK = false>
+template <typename T, bool RES, bool MASK = false, bool XN = false>
 int ln_bwd_t(const void* dy, const void* x, const float* mean, const float* rstd, const float* gm,
              const void* dres, void* dx, float* dg, float* db, int64_t N, int d, hipStream_t st,
-             void* dxm = nullptr, uint32_t mseed = 0, float mp = 0.f) {
-#define GO(D)                                                                                                    \
-    ln_bwd_k<T, D, RES, MASK><<<(ln_grid(N, RowMap<D>::RPW) < 1024 ? ln_grid(N, RowMap<D>::RPW) : 1024), 256, 0, \
-                                st>>>((const T*)dy, (const T*)x, mean, rstd, gm, (const T*)dres, (T*)dx, dg, db, \
-                                      N, (T*)dxm, mseed, mp)
+             void* dxm = nullptr, uint32_t mseed = 0, float mp = 0.f, const float* bt = nullptr, void* xn = nullptr) {
+#define GO(D)                                                                                                        \
+    ln_bwd_k<T, D, RES, MASK, XN><<<(ln_grid(N, RowMap<D>::RPW) < 1024 ? ln_grid(N, RowMap<D>::RPW) : 1024), 256, 0, \
+                                    st>>>((const T*)dy, (const T*)x, mean, rstd, gm, (const T*)dres, (T*)dx, dg, db, \
+                                          N, (T*)dxm, mseed, mp, bt, (T*)xn)
     switch (d) {
         case 128: GO(128); break;
         case 256: GO(256); break;
@@ -433,6 +447,24 @@ extern "C" int hwgat_ln_bwd_masked(const void* dy, const void* x, const float* m
         return ln_bwd_t<float, true, true>(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, N, d, st, dx_masked, mask_seed, mask_p);
     if (dtype == HWGAT_BF16)
         return ln_bwd_t<bf16_t, true, true>(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, N, d, st, dx_masked, mask_seed, mask_p);
+    return HWGAT_EDTYPE;
+}
+
+// hwgat_ln_bwd (+ optional masked copy) that ALSO writes xn = LN(x) (see ln_bwd_k<.., XN>); dres required
+extern "C" int hwgat_ln_bwd_xn(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                               const float* beta, const void* dres, void* dx, float* dgamma, float* dbeta, int64_t N, int d,
+                               int dtype, void* dx_masked, uint32_t mask_seed, float mask_p, void* xn, void* stream) {
+    if (!dy || !x || !mean || !rstd || !gamma || !beta || !dx || !dgamma || !dbeta || !dres || !xn || N <= 0) return HWGAT_EINVAL;
+    if (dx_masked && (mask_p <= 0.f || mask_p >= 1.f)) return HWGAT_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+#define GO(T)                                                                                                             \
+    return dx_masked ? ln_bwd_t<T, true, true, true>(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, N, d, st, dx_masked, \
+                                                     mask_seed, mask_p, beta, xn)                                         \
+                     : ln_bwd_t<T, true, false, true>(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, N, d, st, nullptr, \
+                                                      0, 0.f, beta, xn)
+    if (dtype == HWGAT_F32) { GO(float); }
+    if (dtype == HWGAT_BF16) { GO(bf16_t); }
+#undef GO
     return HWGAT_EDTYPE;
 }
 

@@ -487,11 +487,19 @@ def ln_stats(x, gamma, beta):
     return mean, rstd
 
 
-def ln_backward(dy, x, mean, rstd, gamma, dres, dgamma, dbeta, mask=None):
+def ln_backward(dy, x, mean, rstd, gamma, dres, dgamma, dbeta, mask=None, beta=None):
     """dx = dLN(dy) (+ dres); dgamma/dbeta accumulated in place.  mask = (seed, p): also returns dx * dropout-mask
-    (the gradient in front of the dropout that produced this tensor) -> (dx, dx_masked)."""
+    (the gradient in front of the dropout that produced this tensor) -> (dx, dx_masked).  `beta` given: ALSO returns
+    xn = LN(x) (appended), for the weight-gradient launch of the Linear behind this LayerNorm (hwgat_ln_bwd_xn)."""
     d = x.shape[-1]
     dx = torch.empty_like(x)
+    if beta is not None:
+        dxm = torch.empty_like(x) if mask is not None else None
+        xn = torch.empty_like(x)
+        call("hwgat_ln_bwd_xn", ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(dres), ptr(dx),
+             ptr(dgamma), ptr(dbeta), x.numel() // d, d, dtype_code(x), ptr(dxm), (mask[0] if mask else 0) & 0xFFFFFFFF,
+             float(mask[1]) if mask else 0.0, ptr(xn), stream())
+        return (dx, dxm, xn) if mask is not None else (dx, xn)
     if mask is not None:
         dxm = torch.empty_like(x)
         call("hwgat_ln_bwd_masked", ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(dres), ptr(dx),
@@ -500,6 +508,14 @@ def ln_backward(dy, x, mean, rstd, gamma, dres, dgamma, dbeta, mask=None):
     call("hwgat_ln_bwd", ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(dres), ptr(dx),
          ptr(dgamma), ptr(dbeta), x.numel() // d, d, dtype_code(x), stream())
     return dx
+
+
+def dw_wants_xn(x):
+    """True where the weight-gradient launch of a LayerNorm -> Linear pair takes LN(x) as a plain operand written by the
+    LayerNorm backward (bf16, whole 256-wide tiles: the LDS-DMA kernel gemm_bf16_tn8w.hip) instead of normalising x in its
+    loaders."""
+    d = x.shape[-1]
+    return x.dtype == torch.bfloat16 and d % 256 == 0 and (x.numel() // d) % 128 == 0
 
 
 def transpose(W, dtype=torch.float32):

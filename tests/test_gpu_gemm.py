@@ -628,3 +628,31 @@ def test_bf16_nt8w_every_epilogue_every_element(M, N, K, epi):
     assert float(per_tile.max()) < 3 * tol, float(per_tile.max())
     if ref2 is not None:
         assert rel_err(got2.float().cpu(), ref2.cpu()) < 2 * tol
+
+
+# ---- the eight-wave LDS-DMA bf16 weight-gradient kernel (gemm_bf16_tn8w.hip): N % 256 == K % 256 == 0, M % 128 == 0,
+# plain operands.  dW and db ACCUMULATE (+=); every element against fp64.  Shapes: one iteration per block (prologue /
+# tail waits only), one block, uneven last slice, 1 / 2 / 3 / 4 / 12 dW tiles (split rules), the headline qkv shape.
+@pytest.mark.parametrize("M,N,K", [(128, 256, 256), (256, 256, 256), (128 * 9, 512, 256), (128 * 67, 256, 512),
+                                   (128 * 333, 768, 256), (128 * 41, 512, 512), (128 * 23, 1536, 512), (163840, 1536, 512)])
+def test_bf16_tn8w_weight_and_bias_grad_every_element(M, N, K):
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    dY = torch.randn(M, N, device=DEV, generator=g).bfloat16()
+    X = (torch.randn(M, K, device=DEV, generator=g) + 0.2).bfloat16()
+    dW0 = torch.randn(N, K, device=DEV, generator=g)
+    db0 = torch.randn(N, device=DEV, generator=g)
+    dW, db = dW0.clone(), db0.clone()
+    HF.linear_tn(dY, X, dW, db)
+    ref_w = dW0.double() + dY.double().t() @ X.double()
+    ref_b = db0.double() + dY.double().sum(0)
+    scale_w = (dY.double().t() @ X.double()).norm()
+    assert float((dW.double() - ref_w).norm() / scale_w) < 1e-4          # fp32 accumulation of exact bf16 products
+    assert float((db.double() - ref_b).norm() / dY.double().sum(0).norm()) < 1e-4
+    # tile by tile (a misplaced 256 x 256 tile or a dropped M slice shows up as O(1) on that tile)
+    dt = (dW.double() - ref_w).view(N // 256, 256, K // 256, 256).norm(dim=(1, 3))
+    rt = (ref_w - dW0.double()).view(N // 256, 256, K // 256, 256).norm(dim=(1, 3))
+    assert float((dt / rt).max()) < 1e-3
+    # without a bias gradient
+    dW2 = torch.zeros(N, K, device=DEV)
+    HF.linear_tn(dY, X, dW2, None)
+    assert float((dW2.double() - (ref_w - dW0.double())).norm() / scale_w) < 1e-4

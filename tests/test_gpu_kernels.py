@@ -338,3 +338,33 @@ def test_full_size_properties_config5_head_dim_128():
     xr = qkv[:2, :4].to(torch.bfloat16).cpu().double().requires_grad_(True)
     _oracle_attn(xr, O.window_adjacency(nW), nH, False, None).backward(g2[:2, :4].to(torch.bfloat16).cpu().double())
     assert rel_err(xb.grad[:, :4].float().cpu(), xr.grad) < 1e-2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("d", [128, 256, 512, 1024])
+def test_ln_bwd_xn_also_writes_the_layernorm_output(d, dtype):
+    """hwgat_ln_bwd_xn = hwgat_ln_bwd(_masked) + xn = LN(x) (the plain operand of the weight-gradient launch of the Linear
+    behind the LayerNorm, reference HWGATE.py:203 -> :86, :219 -> :131): dx / dgamma / dbeta / masked copy are what the
+    other entry points write, xn is the LayerNorm forward."""
+    g = torch.Generator().manual_seed(d)
+    L = hw._lib
+    dc = 0 if dtype == torch.float32 else 1
+    n = 777
+    x, dy, res = ((torch.randn(n, d, generator=g) * 1.5 + 0.3).to(DEV).to(dtype) for _ in range(3))
+    w, b = (1 + 0.2 * torch.randn(d, generator=g)).to(DEV), (0.2 * torch.randn(d, generator=g)).to(DEV)
+    mean, rstd = HF.ln_stats(x, w, b)
+    dgr, dbr = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
+    dx0, dxm0 = HF.ln_backward(dy, x, mean, rstd, w, res, dgr, dbr, mask=(99, 0.1))
+    for mask in (None, (99, 0.1)):
+        dg1, db1 = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
+        out = HF.ln_backward(dy, x, mean, rstd, w, res, dg1, db1, mask=mask, beta=b)
+        dx1, xn = out[0], out[-1]
+        assert torch.equal(dx1, dx0)
+        assert torch.allclose(dg1, dgr, rtol=1e-5, atol=1e-4) and torch.allclose(db1, dbr, rtol=1e-5, atol=1e-4)
+        if mask is not None:
+            assert torch.equal(out[1], dxm0)
+        ref = O.layer_norm(x.cpu().double(), w.cpu().double(), b.cpu().double())
+        assert rel_err(xn.float().cpu(), ref) < (F32_TOL if dtype == torch.float32 else BF16_TOL)
+        y = torch.empty_like(x)
+        L.call("hwgat_ln_fwd", L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), L.ptr(mean), L.ptr(rstd), n, d, dc, L.stream())
+        assert rel_err(xn.float().cpu(), y.float().cpu().double()) < (1e-6 if dtype == torch.float32 else 4e-3)
