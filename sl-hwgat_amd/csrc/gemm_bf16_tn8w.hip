@@ -110,19 +110,19 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8w_bf16_k(TnArgsB p) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) bfr[c] = tr_frag(buf * BUFB + kc * (32 * ROWB) + adr_b[c]);
     };
-    // column sums of A for db: wave wk of a group owns column tiles 2 wk, 2 wk + 1 (in the half where they are loaded)
     auto dot8 = [&](const bf16x8& f, float s) {
-        const u32x4 w = __builtin_bit_cast(u32x4, f);
-        s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w.x), ones, s, false);
-        s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w.y), ones, s, false);
-        s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w.z), ones, s, false);
-        return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w.w), ones, s, false);
+        s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 0, 1), ones, s, false);
+        s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 2, 3), ones, s, false);
+        s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 4, 5), ones, s, false);
+        return __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 6, 7), ones, s, false);
     };
-    const bool db_lo = (wk & 1) == 0;                      // wave-uniform: which pair of the loaded half is this wave's
+    // wave wk of a group sums column tile half*4 + wk of every phase (dbacc[half]); uniform branches, static registers
     auto colsum = [&](int half) {
-        if (want_db && (wk >> 1) == half) {
-            if (db_lo) { dbacc[0] = dot8(af[0], dbacc[0]); dbacc[1] = dot8(af[1], dbacc[1]); }
-            else { dbacc[0] = dot8(af[2], dbacc[0]); dbacc[1] = dot8(af[3], dbacc[1]); }
+        if (want_db) {
+            if (wk == 0) dbacc[half] = dot8(af[0], dbacc[half]);
+            else if (wk == 1) dbacc[half] = dot8(af[1], dbacc[half]);
+            else if (wk == 2) dbacc[half] = dot8(af[2], dbacc[half]);
+            else dbacc[half] = dot8(af[3], dbacc[half]);
         }
     };
     auto mfma16 = [&](int half) {
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8w_bf16_k(TnArgsB p) {
             float s = dbacc[e];
             s += __shfl_xor(s, 16, 64);
             s += __shfl_xor(s, 32, 64);
-            if (fq == 0) atomicAdd(p.db + n0 + gm * 128 + (wk * 2 + e) * 16 + fr, s);
+            if (fq == 0) atomicAdd(p.db + n0 + gm * 128 + (e * 4 + wk) * 16 + fr, s);
         }
     }
 }
