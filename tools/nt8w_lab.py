@@ -44,7 +44,7 @@ class use:
 B, T, K = 64, 128, 80
 stages = [int(a) for a in os.environ.get("NT8W_STAGES", "0,1,2").split(",")]
 reps = int(os.environ.get("NT8W_REPS", "10"))
-dt = torch.bfloat16
+dt = torch.float32 if os.environ.get("NT8W_DTYPE", "bf16") == "f32" else torch.bfloat16      # NT8W_DTYPE=f32: the fp32 twin (gemm_f32_nt8w.hip vs gemm_nt256_k)
 
 
 def timed(fn):
@@ -130,7 +130,7 @@ for i in stages:
         to = sorted(x0.elapsed_time(x1) for x0, x1 in ev_o)
         mn, mo = tn[len(tn) // 2] * 1e-3, to[len(to) // 2] * 1e-3
         fl = 2.0 * M * N * Kd
-        byts = 2.0 * M * (Kd + N * (1 + extra + (1 if "gelu'" in name and "saved" in name else 0)))
+        byts = (2.0 if dt == torch.bfloat16 else 4.0) * M * (Kd + N * (1 + extra + (1 if "gelu'" in name and "saved" in name else 0)))
         tot_new += mn * depth
         tot_old += mo * depth
         print(f"s{i} {name:41s} {M:7d} {N:5d} {Kd:5d} | {mn * 1e6:7.1f} ({tn[0] * 1e3:6.1f})  {mo * 1e6:7.1f} ({to[0] * 1e3:6.1f})  {mo / mn:5.2f}x | "
