@@ -61,7 +61,3 @@ int hwgat_launch_tn256(TnArgs a, hipStream_t st);
 // needs M % 256 == N % 256 == K % 32 == 0; same prologues / epilogues as gemm_nt_k
 int hwgat_launch_nt256(const NtArgs& a, int pro, int epi, hipStream_t st);
 
-// defined in gemm_f32_nt8w.hip: the same tile on eight waves (ping-pong), LDS-DMA operand streaming, strip epilogue;
-// M % 256 == N % 256 == K % 64 == 0, no A-side prologue (PRO_NONE / PRO_LN_FOLD)
-bool hwgat_nt8w_f32_takes(const NtArgs& a, int pro, int epi);
-int hwgat_launch_nt8w_f32(const NtArgs& a, int pro, int epi, hipStream_t st);

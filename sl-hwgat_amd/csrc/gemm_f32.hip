@@ -653,11 +653,10 @@ extern "C" int hwgat_linear_nt_f32_ex(const float* A, const float* W, const floa
         const int64_t m256 = M / 256 * 256;
         NtArgs b = a;
         b.M = m256;
-        // ... on the eight-wave ping-pong kernel (gemm_f32_nt8w.hip) where it applies; HWGAT_NT8W=0 (lab builds) keeps the
-        // one-wave-per-SIMD kernel for A/B runs
-        static const bool no8w = [] { const char* e = lab_env("HWGAT_NT8W"); return e && e[0] == '0'; }();
-        const int rc = (!no8w && hwgat_nt8w_f32_takes(b, pro, epi)) ? hwgat_launch_nt8w_f32(b, pro, epi, st)
-                                                                     : hwgat_launch_nt256(b, pro, epi, st);
+        // (an eight-wave ping-pong twin of the bf16 kernel gemm_bf16_nt8w.hip was built and measured in round 3: the same
+        // time within +-2 % on every launch, 55.14 vs 55.39 ms per step -- fp32 MFMA launches are bound by the matrix
+        // pipe at the clock the chip sustains, not by staging or epilogue issue; it lives in tools/f32_nt8w/, not here)
+        const int rc = hwgat_launch_nt256(b, pro, epi, st);
         if (rc || m256 == M) return rc;
         const NtArgs t = nt_rows(a, m256, M - m256);      // 128 rows left: the RAGGED instantiation hashes dropout
         switch (pro) {                                     // masks with the global row index (row0)

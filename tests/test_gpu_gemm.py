@@ -657,71 +657,3 @@ def test_bf16_tn8w_weight_and_bias_grad_every_element(M, N, K):
     HF.linear_tn(dY, X, dW2, None)
     assert float((dW2.double() - (ref_w - dW0.double())).norm() / scale_w) < 1e-4
 
-
-# ---- the fp32 twin (gemm_f32_nt8w.hip): M % 256 == N % 256 == K % 64 == 0; fp32 MFMA arithmetic, every element vs fp64
-@pytest.mark.parametrize("epi", ["none", "bias", "drop_res", "drop_res_stats", "drop_res_merge", "mul_aux", "fold_bias",
-                                 "fold_gelu_g", "gelu_g"])
-@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (256, 256, 512), (512, 768, 128), (256 * 3, 512, 1536), (256 * 37, 256, 192),
-                                   (256 * 130, 512, 128), (256 * 67, 1536, 512)])
-def test_f32_nt8w_every_epilogue_every_element(M, N, K, epi):
-    p = 0.1
-    g = torch.Generator(device=DEV).manual_seed(M * 7 + N + K + len(epi))
-    A = torch.randn(M, K, device=DEV, generator=g)
-    W = torch.randn(N, K, device=DEV, generator=g) * 0.1
-    b = torch.randn(N, device=DEV, generator=g)
-    res = torch.randn(M, N, device=DEV, generator=g) + 0.3
-    aux = torch.randn(M, N, device=DEV, generator=g)
-    gamma, beta = 1 + 0.3 * torch.randn(K, device=DEV, generator=g), 0.3 * torch.randn(K, device=DEV, generator=g)
-    Ad, Wd = A.double(), W.double()
-    lin = Ad @ Wd.t()
-    mask = HF.dropout_mask((M, N), 4321, p, DEV).double()
-    got2 = ref2 = None
-    tol = TOL
-    if epi == "none":
-        got, ref = HF.linear_nt(A, W, None, epi=HF.EPI_NONE), lin
-    elif epi == "bias":
-        got, ref = HF.linear_nt(A, W, b, epi=HF.EPI_BIAS), lin + b.double()
-    elif epi in ("drop_res", "drop_res_stats", "drop_res_merge"):
-        ref = res.double() + (lin + b.double()) * mask
-        if epi == "drop_res":
-            got = HF.linear_nt(A, W, b, epi=HF.EPI_BIAS_DROP_RES, res=res, epi_seed=4321, epi_p=p)
-        else:
-            F, Kt = 4, M // 8
-            merge = (F, Kt) if epi == "drop_res_merge" else None
-            got, mean, rstd = HF.linear_nt(A, W, b, epi=HF.EPI_BIAS_DROP_RES, res=res, epi_seed=4321, epi_p=p, stats=True, merge=merge)
-            if merge:
-                ref = ref.view(2, F // 2, 2, Kt, N).transpose(2, 3).reshape(-1, 2 * N)
-                got = got.reshape(-1, 2 * N)
-            assert rel_err(mean.cpu(), ref.mean(-1).cpu()) < 1e-5
-            assert rel_err(rstd.cpu(), (ref.var(-1, unbiased=False) + 1e-5).rsqrt().cpu()) < 1e-5
-    elif epi == "mul_aux":
-        got, ref = HF.linear_nt(A, W, None, epi=HF.EPI_MUL_AUX, aux=aux), lin * aux.double()
-    else:
-        if epi.startswith("fold"):
-            if K in (128, 256, 512, 1024):
-                ln = HF.ln_stats(A, gamma, beta) + (gamma, beta)
-            else:
-                ln = (Ad.mean(-1).float(), (Ad.var(-1, unbiased=False) + 1e-5).rsqrt().float(), gamma, beta)
-            xn = torch.nn.functional.layer_norm(Ad, (K,), gamma.double(), beta.double())
-            pre = xn @ Wd.t() + b.double()
-            tol = 3e-5
-            if epi == "fold_bias":
-                got, ref = HF.linear_nt_ln(A, W, b, ln), pre
-            else:
-                got, got2 = HF.linear_nt_ln(A, W, b, ln, epi=HF.EPI_BIAS_GELU_DROP_G, epi_seed=4321, epi_p=p)
-        else:
-            pre = lin + b.double()
-            got, got2 = HF.linear_nt(A, W, b, epi=HF.EPI_BIAS_GELU_DROP_G, epi_seed=4321, epi_p=p)
-        if got2 is not None:
-            h = pre.clone().requires_grad_(True)
-            torch.nn.functional.gelu(h).sum().backward()
-            ref, ref2 = torch.nn.functional.gelu(pre) * mask, h.grad * mask
-    assert got.shape == ref.shape
-    assert bool(torch.isfinite(got).all())
-    assert rel_err(got.cpu(), ref.cpu()) < tol
-    gt, rt = got.reshape(-1, ref.shape[-1]), ref.reshape(-1, ref.shape[-1])
-    per_tile = ((gt.double() - rt).reshape(rt.shape[0] // 128, 128, -1, 256).norm(dim=(1, 3)) /
-                rt.reshape(rt.shape[0] // 128, 128, -1, 256).norm(dim=(1, 3)))
-    assert float(per_tile.max()) < 3 * tol, float(per_tile.max())
-    if ref2 is not None:
-        assert rel_err(got2.cpu(), ref2.cpu()) < 2 * tol
