@@ -29,13 +29,18 @@ from . import functional as HF
 # Measured on MI355X (config 2, fp32): 553.5 vs 552.4 clips/s -- no gain, both kinds of kernel use
 # persistent full-chip grids; kept as an opt-in module switch (set block.OVERLAP_DW = True), off by default.
 OVERLAP_DW = False
+SIDE_CUS = 0            # > 0: the side stream owns this many CUs (SIDE_CUS / 8 on every XCD), see streams.py
 _SIDE = {}
 
 
 def _side_stream(device):
-    key = (device.type, device.index)
+    key = (device.type, device.index, SIDE_CUS)
     if key not in _SIDE:
-        _SIDE[key] = torch.cuda.Stream(device)
+        if SIDE_CUS > 0:
+            from .streams import cu_mask, masked_stream
+            _SIDE[key] = masked_stream(device, cu_mask(0, SIDE_CUS))
+        else:
+            _SIDE[key] = torch.cuda.Stream(device)
     return _SIDE[key]
 
 
