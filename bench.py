@@ -462,10 +462,6 @@ def main():
     ap.add_argument("--no-kernel-timers", action="store_true", help="skip the per-launch HIP events (A/B runs)")
     ap.add_argument("--timer-every", type=int, default=4,
                     help="record the per-launch HIP events on every N-th step of the timed region (1 = every step)")
-    ap.add_argument("--dw-side-cus", type=int, default=None,
-                    help="experiment: issue the weight-gradient GEMMs on a side stream that owns this many CUs (multiple of 8; "
-                         "0 = an unrestricted side stream); with --main-cus-rest the step itself runs on a stream that owns the others")
-    ap.add_argument("--main-cus-rest", action="store_true")
     ap.add_argument("--eval-mode", action="store_true", help="deterministic fwd+bwd (no dropout / attention drop)")
     ap.add_argument("--from-host", action="store_true",
                     help="feed every step from host samples through collate.PinnedBatcher (pinned staging + async H2D): "
@@ -535,14 +531,6 @@ def main():
     opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=5e-4, fused=True)
     step = train_mod.TrainStep(model, opt, reducer, micro_batch=args.micro_batch)
 
-    main_stream = None
-    if args.dw_side_cus is not None:
-        blk_mod = import_module("sl-hwgat_amd.block")
-        blk_mod.OVERLAP_DW, blk_mod.SIDE_CUS = True, args.dw_side_cus
-        args.no_kernel_timers = True                      # per-launch events serialise the two streams
-        if args.main_cus_rest and args.dw_side_cus > 0:
-            st_mod = import_module("sl-hwgat_amd.streams")
-            main_stream = st_mod.masked_stream(dev, st_mod.cu_mask(args.dw_side_cus, 256))
     g = torch.Generator(device=dev).manual_seed(7 + rank)
     x = torch.rand(c["B"], c["T"], c["J"], c["C"], device=dev, generator=g)
     y = torch.randint(0, c["nc"], (c["B"],), device=dev, generator=g)
@@ -560,12 +548,6 @@ def main():
         def run_step():
             xb, yb = batcher.collate(samples)
             step(xb, yb)
-    elif main_stream is not None:
-        def run_step():
-            main_stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(main_stream):
-                step(x, y)
-            torch.cuda.current_stream().wait_stream(main_stream)
     else:
         def run_step():
             step(x, y)
@@ -698,7 +680,6 @@ def main():
                                       if args.from_host else ""),
                        "global_batch": world * c["B"], "parallelism": f"dp{world}"},
             "roofline": roof, "roofline_end_to_end": roof_e2e,
-            "dw_side_stream": ({"side_cus": args.dw_side_cus, "main_on_the_rest": bool(main_stream)} if args.dw_side_cus is not None else None),
             "kernels": kern, "other_hip_entry_points": others,
             "hip_kernel_ms_per_step": round(hip_ms / n_timed, 3), "kernel_timer_steps": n_timed,
             "loss": round(loss, 4),

@@ -28,19 +28,18 @@ from . import functional as HF
 # its HBM-bound kernels (attention backward, LayerNorm backward).  Joined before backward returns.
 # Measured on MI355X (config 2, fp32): 553.5 vs 552.4 clips/s -- no gain, both kinds of kernel use
 # persistent full-chip grids; kept as an opt-in module switch (set block.OVERLAP_DW = True), off by default.
+# Round 3 also gave the side stream its own CUs (hipExtStreamCreateWithCUMask: k CUs of every XCD, the main stream on all
+# or on the rest): 32 / 64 / 96 CUs -> 206 / 328 / 396 clips/s against 627 (profiles/r03_cu_split_sweep.json, code at
+# commit 183be5b): the step is throughput-bound on the matrix pipes, so a partition only lengthens the dW launches, which
+# every block's backward joins before it returns.  Dropped.
 OVERLAP_DW = False
-SIDE_CUS = 0            # > 0: the side stream owns this many CUs (SIDE_CUS / 8 on every XCD), see streams.py
 _SIDE = {}
 
 
 def _side_stream(device):
-    key = (device.type, device.index, SIDE_CUS)
+    key = (device.type, device.index)
     if key not in _SIDE:
-        if SIDE_CUS > 0:
-            from .streams import cu_mask, masked_stream
-            _SIDE[key] = masked_stream(device, cu_mask(0, SIDE_CUS))
-        else:
-            _SIDE[key] = torch.cuda.Stream(device)
+        _SIDE[key] = torch.cuda.Stream(device)
     return _SIDE[key]
 
 
