@@ -8,18 +8,22 @@
 //   * operands go HBM/L2 -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`): no staging registers, no ds_write pass, the
 //     loads of the next five phases stay in flight across barriers behind COUNTED `s_waitcnt vmcnt(6)` (never 0 in the
 //     steady state), workgroup barriers are raw `s_barrier` (a __syncthreads() would drain the DMA queue);
-//   * EIGHT waves per 256x256 tile, two per SIMD, in a ping-pong: waves 0-3 (rows 0-127 of the tile) and waves 4-7
-//     (rows 128-255) are offset by one barrier, so while one wave of a SIMD runs its 16-MFMA cluster its partner issues
+//   * EIGHT waves per 256x256 tile, two per SIMD, in a ping-pong: waves 0-3 (columns 0-127 of the tile) and waves 4-7
+//     (columns 128-255) are offset by one barrier, so while one wave of a SIMD runs its 16-MFMA cluster its partner issues
 //     its LDS fragment reads and its share of the DMA for a later K-tile;
-//   * the product is formed TRANSPOSED (MFMA A operand = weight rows, B operand = activation rows), and the weight rows
-//     are dealt to the four 16-row MFMA tiles of a wave so that a lane ends up with 16 CONSECUTIVE output columns of one
-//     output row; the epilogue runs with two waves per SIMD sharing the vector pipe.
+//   * the epilogue needs NO LDS and every global access of it is whole lines: MFMA B-operand column j = lane & 15 is
+//     weight row  n = (lane & 15) * 8 + t  for the wave's eight 16-column tiles t, so a lane ends with 8 CONSECUTIVE
+//     output columns (16 bytes of bf16) of each of its rows, 16 neighbouring lanes = 256 contiguous bytes, four rows per
+//     instruction; the residual / auxiliary operand is read in the same shape.  (Round-3 history: a transposed product
+//     with direct stores issued 64 separate 16-byte requests per instruction, 6.7 us of store tail per tile; turning the
+//     accumulators through wave-private LDS strips fixed the requests but cost 256 KiB of ds_write_b128 per tile at
+//     ~80 B/clk/CU -- as long.  The weight-row deal makes the turn unnecessary.)
 //
-// (the epilogue turns each 16-row piece through a wave-private LDS strip so that its global accesses are whole lines)
 // LDS image of one K-tile (BK = 64): activations [256 rows][128 B] | weights [256 rows][128 B], 16-byte chunks of a row
-// XOR-swizzled so that every ds_read_b128 fragment read is bank-conflict free; the DMA writes LDS linearly (wave base +
-// lane x 16 B), so the swizzle is applied to the per-lane SOURCE address (8 rows x 128 B = whole lines per piece).  Two
-// K-tile buffers (128 KiB) + 32 KiB of epilogue strips.
+// XOR-swizzled by (row & 7) so that every ds_read_b128 fragment read is bank-conflict free; the DMA writes LDS linearly
+// (wave base + lane x 16 B), so swizzle AND the weight-row deal are applied to the per-lane SOURCE address (a piece =
+// 8 rows x 128 B, whole lines).  Weight rows sit tile-major: LDS row (n>>7)*128 + (n&7)*16 + ((n>>3)&15) holds weight row
+// n of the tile, i.e. the 16 rows of one MFMA tile are consecutive.  Two K-tile buffers (128 KiB) + 4 KiB row statistics.
 //
 // Needs M % 256 == N % 256 == K % 128 == 0, no A-side prologue (PRO_NONE or the folded LayerNorm); everything else stays
 // on gemm_nt256_bf16_k / gemm_nt_bf16_k (hwgat_linear_nt_bf16 decides).
@@ -34,8 +38,8 @@ constexpr int BT = 256, BK = 64;
 constexpr int ROWB = 2 * BK;                  // bytes of one LDS row (one K-tile of one matrix row)
 constexpr int OPB = BT * ROWB;                // one operand tile: 32 KiB
 constexpr int BUFB = 2 * OPB;                 // activations | weights of one K-tile: 64 KiB
-constexpr int STRIP_OFF = 2 * BUFB;           // epilogue: one 16-row x 64-fp32 strip per wave (the row statistics alias them)
-constexpr int SMEM = STRIP_OFF + 8 * 16 * 256;   // 160 KiB, all of the CU's LDS
+constexpr int STAT_OFF = 2 * BUFB;            // row statistics: [2 column halves][256 rows] x (sum, sum of squares)
+constexpr int SMEM = STAT_OFF + 2 * BT * 2 * 4;
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
@@ -55,7 +59,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8w_bf16_k(NtArgsB p) {
     __shared__ __attribute__((aligned(16))) unsigned char smb[SMEM];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int gm = wave >> 2, wn = wave & 3;               // ping-pong group = row half of the tile; column quarter
+    const int gm = wave >> 2, wm = wave & 3;               // ping-pong group = column half of the tile; row quarter
     const int fr = lane & 15, fq = lane >> 4;
     const int tiles_n = p.N / BT;
     const int row_blocks = (int)(p.M / BT);
@@ -79,37 +83,32 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8w_bf16_k(NtArgsB p) {
         n0 = nt * BT;
     };
 
-    // ---- LDS-DMA staging.  A stage = 16 pieces of 8 rows x 128 B; this wave issues two of them.
-    // activations, half h (rows h*64 .. h*64+63 of BOTH row halves of the tile): this wave's pieces are rows
-    //   gm*128 + h*64 + ((wave&3)*2 + j)*8 .. +7;   weights, half h (the rows the t in {2h, 2h+1} MFMA tiles of every
-    //   wave read): rows (wave>>1)*64 + ((wave&1)*2 + j)*16 + h*8 .. +7.
-    // per-lane source offset inside a piece: row (lane>>3), 16-byte chunk (lane&7) ^ key(row) -- the read side applies
-    // the same XOR.  key = row & 7 for activations; for weights key = ((row>>4)&3)*2 + ((row>>1)&1), which is what makes
-    // the permuted row set of a weight fragment (below) conflict free.
+    // ---- LDS-DMA staging.  A stage = 16 pieces of 8 LDS rows x 128 B; this wave issues two of them.  Lane l of a piece
+    // writes LDS row (l>>3), 16-byte chunk (l&7) and fetches chunk (l&7) ^ (l>>3) of the matrix row that belongs there (the
+    // read side applies the same XOR; pieces start at multiples of 8 rows).
+    //   activations, half h: LDS rows = tile rows wm'*64 + h*32 + q*8 .. +7 for every row quarter wm' (what the mt in
+    //     {2h, 2h+1} fragments of all waves read): this wave's pieces are wm' = wave>>1, q = (wave&1)*2 + j;
+    //   weights, half h: the LDS rows of column tiles t in {4h .. 4h+3} of both column halves: this wave's pieces are
+    //     half g' = wave>>2, tile t = 4h + (wave&3), LDS rows g'*128 + t*16 + j*8 .. +7 = weight rows g'*128 + (j*8 + l>>3)*8 + t.
     const int pr = lane >> 3;
     const int voff_x = pr * K2 + (((lane & 7) ^ pr) << 4);
-    int voff_w[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int fqp = (wave & 1) * 2 + j;
-        voff_w[j] = pr * K2 + (((lane & 7) ^ (fqp * 2 + ((lane >> 4) & 1))) << 4);
-    }
-    auto x_row = [&](int h, int j) { return gm * 128 + h * 64 + ((wave & 3) * 2 + j) * 8; };
-    auto w_row = [&](int h, int j) { return (wave >> 1) * 64 + ((wave & 1) * 2 + j) * 16 + h * 8; };
+    const int voff_w = pr * 8 * K2 + (((lane & 7) ^ pr) << 4);
     auto stage_x = [&](int buf, int h, __amdgpu_buffer_rsrc_t rs, int kb) {
         if constexpr (DBG >= 3) return;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int r = x_row(h, j);
+            const int r = (wave >> 1) * 64 + h * 32 + ((wave & 1) * 2 + j) * 8;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(smb + buf * BUFB + r * ROWB), 16, voff_x, r * K2 + kb, 0, 0);
         }
     };
     auto stage_w = [&](int buf, int h, __amdgpu_buffer_rsrc_t rs, int kb) {
         if constexpr (DBG >= 3) return;
+        const int tt = 4 * h + (wave & 3);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int r = w_row(h, j);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(smb + buf * BUFB + OPB + r * ROWB), 16, voff_w[j], r * K2 + kb, 0, 0);
+            const int rho = (wave >> 2) * 128 + tt * 16 + j * 8;             // LDS row
+            const int n = (wave >> 2) * 128 + j * 64 + tt;                   // weight row of the piece's first lane
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(smb + buf * BUFB + OPB + rho * ROWB), 16, voff_w, n * K2 + kb, 0, 0);
         }
     };
     auto rsrc_x = [&](int64_t m0) {
@@ -119,16 +118,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8w_bf16_k(NtArgsB p) {
         return __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (int64_t)n0 * p.K), 0, 0x7fffffff, 0x00020000);
     };
 
-    // ---- fragment reads.  Activation fragment (mt, kc): row gm*128 + mt*16 + fr, chunk kc*4 + fq.  Weight fragment (t, kc):
-    // MFMA row i = fr reads weight row wn*64 + (fr>>2)*16 + t*4 + (fr&3), so accumulator register r of lane (fr, fq) is
-    // output column wn*64 + fq*16 + t*4 + r: the four tiles t interleave to 16 consecutive columns per lane.
-    const int lx[2] = {gm * (128 * ROWB) + fr * ROWB + (((0 + fq) ^ (fr & 7)) << 4),
-                       gm * (128 * ROWB) + fr * ROWB + (((4 + fq) ^ (fr & 7)) << 4)};
-    const int wkey = (fr >> 2) * 2 + ((fr >> 1) & 1);
-    const int wrow = wn * 64 + (fr >> 2) * 16 + (fr & 3);
-    const int lw[2] = {OPB + wrow * ROWB + (((0 + fq) ^ wkey) << 4), OPB + wrow * ROWB + (((4 + fq) ^ wkey) << 4)};
+    // ---- fragment reads.  MFMA A operand (rows i): activation row wm*64 + mt*16 + fr; B operand (columns j): LDS weight row
+    // gm*128 + t*16 + fr = weight row gm*128 + fr*8 + t.  Chunk kc*4 + fq of either, XOR (fr & 7).  Accumulator register r of
+    // lane (fr, fq), tile (mt, t): row wm*64 + mt*16 + fq*4 + r, column gm*128 + fr*8 + t.
+    const int lx[2] = {(wm * 64 + fr) * ROWB + (((0 + fq) ^ (fr & 7)) << 4), (wm * 64 + fr) * ROWB + (((4 + fq) ^ (fr & 7)) << 4)};
+    const int lw[2] = {OPB + (gm * 128 + fr) * ROWB + (((0 + fq) ^ (fr & 7)) << 4), OPB + (gm * 128 + fr) * ROWB + (((4 + fq) ^ (fr & 7)) << 4)};
 
-    f32x4 acc[8][4];
+    f32x4 acc[4][8];
     bf16x8 xf[4][2], wf[4][2];
     if constexpr (DBG >= 4) {
 #pragma unroll
@@ -136,31 +132,31 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8w_bf16_k(NtArgsB p) {
 #pragma unroll
             for (int kc = 0; kc < 2; ++kc) { xf[i][kc] = bf16x8{}; wf[i][kc] = bf16x8{}; }
     }
-    auto read_x = [&](int buf, int half) {
-        if constexpr (DBG >= 4) return;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int kc = 0; kc < 2; ++kc)
-                xf[i][kc] = *reinterpret_cast<const bf16x8*>(smb + buf * BUFB + lx[kc] + (half * 4 + i) * (16 * ROWB));
-    };
-    auto read_w = [&](int buf, int half) {
+    auto read_x = [&](int buf, int half) {                  // row tiles mt = 2 half, 2 half + 1
         if constexpr (DBG >= 4) return;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int kc = 0; kc < 2; ++kc)
-                wf[half * 2 + i][kc] = *reinterpret_cast<const bf16x8*>(smb + buf * BUFB + lw[kc] + (half * 2 + i) * (4 * ROWB));
+                xf[half * 2 + i][kc] = *reinterpret_cast<const bf16x8*>(smb + buf * BUFB + lx[kc] + (half * 2 + i) * (16 * ROWB));
+    };
+    auto read_w = [&](int buf, int half) {                  // column tiles t = 4 half .. 4 half + 3, always into wf[0..3]
+        if constexpr (DBG >= 4) return;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc)
+                wf[i][kc] = *reinterpret_cast<const bf16x8*>(smb + buf * BUFB + lw[kc] + (half * 4 + i) * (16 * ROWB));
     };
     auto mfma16 = [&](int mh, int th) {                     // quadrant (row half mh of the wave tile, column half th) x K = 64
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kc = 0; kc < 2; ++kc)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
-                    acc[mh * 4 + i][th * 2 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[th * 2 + t][kc], xf[i][kc], acc[mh * 4 + i][th * 2 + t], 0, 0, 0);
+                for (int t = 0; t < 4; ++t)
+                    acc[mh * 2 + i][th * 4 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[mh * 2 + i][kc], wf[t][kc], acc[mh * 2 + i][th * 4 + t], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
     };
 
@@ -180,16 +176,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8w_bf16_k(NtArgsB p) {
     __amdgpu_buffer_rsrc_t xc = rsrc_x(m0), wc = rsrc_w(n0), xn = xc, wnx = wc;
 
     // ---- prologue: what phases 3..8 of a previous iteration would have issued for this tile's first two K-tiles
-    stage_x(0, 0, xc, 0); stage_w(0, 0, wc, 0); stage_w(0, 1, wc, 0); stage_x(0, 1, xc, 0);
+    stage_x(0, 0, xc, 0); stage_w(0, 0, wc, 0); stage_x(0, 1, xc, 0); stage_w(0, 1, wc, 0);
     stage_x(1, 0, xc, 2 * BK); stage_w(1, 0, wc, 2 * BK);
     wait_vm<4>();                                           // K-tile 0 has landed (this wave's pieces) ...
     wg_barrier();                                           // ... and everyone's
 
     while (true) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         stamp(0);
         if (gm == 1) wg_barrier();                          // waves 4-7 run one barrier behind waves 0-3
         stamp(1);
@@ -208,65 +204,61 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8w_bf16_k(NtArgsB p) {
             }
             const int kb_c = (2 * it + 1) * (2 * BK);       // the current pair's second K-tile
 
-            // one phase = { fragment reads + one DMA stage + counted wait | barrier | 16 MFMAs | barrier }.
-            // A stage issued in phase q is first read in phase q + 5; the wait of phase q + 3 (after that phase's own
-            // issue: three younger stages = 6 DMA instructions may stay in flight) retires it, the barrier behind it makes
-            // every wave's pieces visible, one whole phase before the first read.
+            // one phase = { fragment reads + one DMA stage + counted wait | barrier | 16 MFMAs | barrier }.  Quadrant order
+            // (X0,W0) (X1,W0) (X1,W1) (X0,W1): both activation halves stay in registers, the weight halves share theirs.
+            // A stage issued in phase q is first read in phase q + 5 or later; the wait of phase q + 3 (after that phase's
+            // own issue: three younger stages = 6 DMA instructions may stay in flight) retires it, the barrier behind it
+            // makes every wave's pieces visible, one whole phase before the first read.  A region is restaged two or
+            // more phases after its last read.
 #define HWGAT_WAIT(NLAST) do { if constexpr (DBG < 2) { if (more) wait_vm<6>(); else wait_vm<NLAST>(); } } while (0)
-            // phase 1: quadrant (0,0) of K-tile A (buffer 0)
+            // phase 1: K-tile A (buffer 0), quadrant (X0, W0)
             read_x(0, 0); read_w(0, 0);
-            stage_w(1, 1, wc, kb_c);
-            HWGAT_WAIT(6);
-            wg_barrier(); wait_lds(); __builtin_amdgcn_sched_barrier(0); mfma16(0, 0); wg_barrier();
-            // phase 2: quadrant (0,1)
-            read_w(0, 1);
             stage_x(1, 1, xc, kb_c);
             HWGAT_WAIT(6);
-            wg_barrier(); wait_lds(); __builtin_amdgcn_sched_barrier(0); mfma16(0, 1); wg_barrier();
-            // phase 3: quadrant (1,1)
+            wg_barrier(); wait_lds(); __builtin_amdgcn_sched_barrier(0); mfma16(0, 0); wg_barrier();
+            // phase 2: (X1, W0)
             read_x(0, 1);
+            stage_w(1, 1, wc, kb_c);
+            HWGAT_WAIT(6);
+            wg_barrier(); wait_lds(); __builtin_amdgcn_sched_barrier(0); mfma16(1, 0); wg_barrier();
+            // phase 3: (X1, W1)
+            read_w(0, 1);
             if (more) stage_x(0, 0, xn, kb_n);
             HWGAT_WAIT(4);
             wg_barrier(); wait_lds(); __builtin_amdgcn_sched_barrier(0); mfma16(1, 1); wg_barrier();
-            // phase 4: quadrant (1,0) -- the column-half-0 weight fragments are still in registers
+            // phase 4: (X0, W1) -- nothing to read
             if (more) stage_w(0, 0, wnx, kb_n);
             HWGAT_WAIT(2);
-            wg_barrier(); __builtin_amdgcn_sched_barrier(0); mfma16(1, 0); wg_barrier();
+            wg_barrier(); __builtin_amdgcn_sched_barrier(0); mfma16(0, 1); wg_barrier();
             // phases 5-8: the same on K-tile B (buffer 1)
             read_x(1, 0); read_w(1, 0);
-            if (more) stage_w(0, 1, wnx, kb_n);
-            HWGAT_WAIT(0);
-            wg_barrier(); wait_lds(); __builtin_amdgcn_sched_barrier(0); mfma16(0, 0); wg_barrier();
-            read_w(1, 1);
             if (more) stage_x(0, 1, xn, kb_n);
             HWGAT_WAIT(0);
-            wg_barrier(); wait_lds(); __builtin_amdgcn_sched_barrier(0); mfma16(0, 1); wg_barrier();
+            wg_barrier(); wait_lds(); __builtin_amdgcn_sched_barrier(0); mfma16(0, 0); wg_barrier();
             read_x(1, 1);
+            if (more) stage_w(0, 1, wnx, kb_n);
+            HWGAT_WAIT(0);
+            wg_barrier(); wait_lds(); __builtin_amdgcn_sched_barrier(0); mfma16(1, 0); wg_barrier();
+            read_w(1, 1);
             if (more) stage_x(1, 0, xn, kb_n + 2 * BK);
             HWGAT_WAIT(0);
             wg_barrier(); wait_lds(); __builtin_amdgcn_sched_barrier(0); mfma16(1, 1); wg_barrier();
             if (more) stage_w(1, 0, wnx, kb_n + 2 * BK);
             HWGAT_WAIT(0);
-            wg_barrier(); __builtin_amdgcn_sched_barrier(0); mfma16(1, 0); wg_barrier();
+            wg_barrier(); __builtin_amdgcn_sched_barrier(0); mfma16(0, 1); wg_barrier();
 #undef HWGAT_WAIT
         }
         stamp(2);
         if (gm == 0) wg_barrier();                          // waves 0-3 wait for the partner's last cluster: both groups
                                                             // run the epilogue together (two waves per SIMD share the vector pipe)
 
-        // ---- epilogue.  acc[mt][t][r] is row m0 + gm*128 + mt*16 + fr, column n0 + wn*64 + fq*16 + t*4 + r: the four lanes
-        // that hold one output row are 16 lanes apart, and a store / load instruction whose neighbouring lanes touch
-        // different rows is issued as 64 separate 16-byte requests (measured: 6.7 us of store tail per tile, a third of a
-        // K = 512 tile).  So each 16-row piece first turns through a WAVE-PRIVATE 4 KiB LDS strip (16 rows x 64 fp32,
-        // 16-byte chunks XOR-swizzled by the row: conflict-free both ways, no barrier -- a wave's DS operations execute in
-        // order), after which lane l owns row (l>>3) of 8-row pass ps, columns (l&7)*8 .. +7: eight neighbouring lanes
-        // = one whole 128-byte line of C (and of the residual / auxiliary operand), 8 lines per instruction.
+        // ---- epilogue, straight from the accumulators: acc[mt][t][r] is row m0 + wm*64 + mt*16 + fq*4 + r, column
+        // n0 + gm*128 + fr*8 + t -- a lane's eight tiles t of one (mt, r) are 8 consecutive columns (16 bytes), the 16 lanes
+        // fr of a row 256 contiguous bytes, an instruction = 4 whole-line row segments.
         {
             const uint32_t epi_th = drop_thresh(p.epi_p);
             const float epi_sc = 1.0f / (1.0f - p.epi_p);
-            const int er = lane >> 3, ec = (lane & 7) * 8;
-            const int col = n0 + wn * 64 + ec;
-            unsigned char* strip = smb + STRIP_OFF + wave * (16 * 256);
+            const int col = n0 + gm * 128 + fr * 8;
             float cb[8], cs[8];                             // bias (or c_n of the folded LayerNorm); s_n of the fold
 #pragma unroll
             for (int e = 0; e < 8; ++e) { cb[e] = 0.f; cs[e] = 0.f; }
@@ -289,39 +281,26 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8w_bf16_k(NtArgsB p) {
                 }
             }
             stamp(3);
-            float st1[16], st2[16];                         // row statistics of this lane's 16 (piece, pass) rows
-            MergeWalk mw;
-            if constexpr (STAT == X_STAT_MERGE) mw.start(m0 + gm * 128 + er, p.mg_F, p.mg_K, 8);
+            float* rowstat = reinterpret_cast<float*>(smb + STAT_OFF);
 #pragma unroll
-            for (int mt = 0; mt < 8; ++mt) {
-                // the residual / auxiliary operand of both passes is requested before the piece is parked
-                u32x4 ex[2];
+            for (int mt = 0; mt < 4; ++mt) {
+                const int64_t row0 = m0 + wm * 64 + mt * 16 + fq * 4;
+                // the residual / auxiliary operand of the piece's four rows is requested before any of it is used
+                u32x4 ex[4];
                 if constexpr (epi_reads_extra(EPI)) {
-                    const bf16_t* src = (EPI == EPI_BIAS_DROP_RES ? p.res : p.aux) + (m0 + gm * 128 + mt * 16 + er) * p.N + col;
-                    ex[0] = *reinterpret_cast<const u32x4*>(src);
-                    ex[1] = *reinterpret_cast<const u32x4*>(src + 8 * (int64_t)p.N);
+                    const bf16_t* src = (EPI == EPI_BIAS_DROP_RES ? p.res : p.aux) + row0 * p.N + col;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ex[r] = *reinterpret_cast<const u32x4*>(src + r * (int64_t)p.N);
                 }
+                MergeWalk mw;
+                if constexpr (STAT == X_STAT_MERGE) mw.start(row0, p.mg_F, p.mg_K, 1);
 #pragma unroll
-                for (int tt = 0; tt < 4; ++tt)
-                    *reinterpret_cast<f32x4*>(strip + fr * 256 + (((fq * 4 + tt) ^ fr) << 4)) = acc[mt][tt];
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // other lanes' writes, this lane's reads: keep the order
-                __builtin_amdgcn_wave_barrier();
-                f32x4 pv[2][2];
-#pragma unroll
-                for (int ps = 0; ps < 2; ++ps) {
-                    const int R = ps * 8 + er;
-                    pv[ps][0] = *reinterpret_cast<const f32x4*>(strip + R * 256 + (((ec >> 2) ^ R) << 4));
-                    pv[ps][1] = *reinterpret_cast<const f32x4*>(strip + R * 256 + ((((ec >> 2) + 1) ^ R) << 4));
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // ... and the next piece's writes behind these reads
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int ps = 0; ps < 2; ++ps) {
-                    const int R = ps * 8 + er;
-                    const int64_t row = m0 + gm * 128 + mt * 16 + R;
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t row = row0 + r;
                     const int64_t off = row * p.N + col;
-                    const f32x4 v0 = pv[ps][0], v1 = pv[ps][1];
-                    float o[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    float o[8];
+#pragma unroll
+                    for (int tt = 0; tt < 8; ++tt) o[tt] = acc[mt][tt][r];
                     if constexpr (STAT == X_LNFOLD) {
                         const float rr = p.rstd[row], tm = p.mean[row] * rr;
 #pragma unroll
@@ -340,7 +319,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8w_bf16_k(NtArgsB p) {
                     }
                     if constexpr (EPI == EPI_BIAS_DROP_RES) {
                         float rs[8];
-                        unpack8(ex[ps], rs);
+                        unpack8(ex[r], rs);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) o[e] = rs[e] + o[e] * dk[e];
                     } else if constexpr (EPI == EPI_BIAS_GELU_DROP) {
@@ -357,12 +336,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8w_bf16_k(NtArgsB p) {
                         *reinterpret_cast<u32x4*>(p.C2 + off) = pack8(g8);
                     } else if constexpr (EPI == EPI_MUL_AUX) {
                         float h[8];
-                        unpack8(ex[ps], h);
+                        unpack8(ex[r], h);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) o[e] *= h[e];
                     } else if constexpr (EPI == EPI_GELU_BWD) {
                         float h[8];
-                        unpack8(ex[ps], h);
+                        unpack8(ex[r], h);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) o[e] = o[e] * dk[e] * gelu_grad(h[e]);
                     }
@@ -373,8 +352,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8w_bf16_k(NtArgsB p) {
                         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) { s1 += q[e]; s2 += q[e] * q[e]; }
-                        st1[mt * 2 + ps] = group_sum<8>(s1);
-                        st2[mt * 2 + ps] = group_sum<8>(s2);
+                        s1 = group_sum<16>(s1); s2 = group_sum<16>(s2);
+                        if (fr == 0) {
+                            f32x2 st = {s1, s2};
+                            *reinterpret_cast<f32x2*>(rowstat + (gm * BT + wm * 64 + mt * 16 + fq * 4 + r) * 2) = st;
+                        }
                     }
                     bf16_t* dst = p.C + off;
                     if constexpr (STAT == X_STAT_MERGE) { dst = p.C + mw.off(p.N) + col; mw.next(); }
@@ -383,29 +365,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8w_bf16_k(NtArgsB p) {
                 }
             }
             if constexpr (STAT == X_STAT || STAT == X_STAT_MERGE) {
-                // [4 column quarters][256 rows] x (sum, sum of squares) in the strip area, once every wave is done with its strip
-                float* rowstat = reinterpret_cast<float*>(smb + STRIP_OFF);
                 wait_lds();
                 wg_barrier();
-                if ((lane & 7) == 0) {
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        f32x2 st = {st1[q], st2[q]};
-                        *reinterpret_cast<f32x2*>(rowstat + (wn * BT + gm * 128 + (q >> 1) * 16 + (q & 1) * 8 + er) * 2) = st;
-                    }
-                }
-                wait_lds();
-                wg_barrier();
-                if (tid < BT) {                             // fixed order over the four column quarters, one atomic per row and tile
+                if (tid < BT) {                             // the two column halves in a fixed order, one atomic per row and tile
                     int64_t mr = m0 + tid;
                     if constexpr (STAT == X_STAT_MERGE) { MergeWalk w; w.start(m0 + tid, p.mg_F, p.mg_K, 1); mr = w.mrow(); }
-                    const float a1 = (rowstat[2 * tid] + rowstat[2 * (BT + tid)]) + (rowstat[2 * (2 * BT + tid)] + rowstat[2 * (3 * BT + tid)]);
-                    const float a2 = (rowstat[2 * tid + 1] + rowstat[2 * (BT + tid) + 1]) + (rowstat[2 * (2 * BT + tid) + 1] + rowstat[2 * (3 * BT + tid) + 1]);
-                    atomicAdd(p.stat_sum + mr, a1);
-                    atomicAdd(p.stat_sq + mr, a2);
+                    atomicAdd(p.stat_sum + mr, rowstat[2 * tid] + rowstat[2 * (BT + tid)]);
+                    atomicAdd(p.stat_sq + mr, rowstat[2 * tid + 1] + rowstat[2 * (BT + tid) + 1]);
                 }
                 wait_lds();
-                wg_barrier();                               // the strips are rewritten by the next tile's epilogue
+                wg_barrier();                               // the scratch is rewritten by the next tile's epilogue
             }
         }
         stamp(4);
