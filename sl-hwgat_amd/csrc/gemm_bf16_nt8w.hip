@@ -67,17 +67,20 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8w_bf16_k(NtArgsB p) {
     const int n_it = p.K / (2 * BK);                        // main-loop iterations per tile: two K-tiles each
     const int K2 = p.K * 2;                                 // bytes per matrix row
 
-    // ---- tile order: every block walks a CONTIGUOUS run of tiles, n-tile fastest: the column tiles of one 256-row block of
-    // the activations are taken one after the other by the SAME block, so the row block streams from HBM once and its
-    // re-reads (N / 256 - 1 of them) hit this XCD's L2 while the lines are hot.  (The round-robin order of gemm_nt_k --
-    // the n-tiles of a row block on different CUs of one XCD at the same time -- measured 1.06-1.28x the algorithmic HBM
-    // bytes here, profiles/r03_gemm_bf16_pmc_traffic.json: with eight waves per CU the tiles of a row block drift apart.)
-    const int per_block = (n_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int t_end = (blockIdx.x + 1) * per_block < n_tiles ? (blockIdx.x + 1) * per_block : n_tiles;
+    // ---- tile order: XCD-aware (the n-tiles of a 256-row block run on one XCD at the same time), see gemm_nt_k
+    const int swz_tiles = (row_blocks / 8) * 8 * tiles_n;
     auto tile_origin = [&](int t, int64_t& m0, int& n0) {
-        const int rb = t / tiles_n;
+        int rb, nt;
+        if (t < swz_tiles) {
+            rb = (t / (8 * tiles_n)) * 8 + (t & 7);
+            nt = (t >> 3) % tiles_n;
+        } else {
+            const int w = t - swz_tiles;
+            rb = (row_blocks / 8) * 8 + w / tiles_n;
+            nt = w % tiles_n;
+        }
         m0 = (int64_t)rb * BT;
-        n0 = (t - rb * tiles_n) * BT;
+        n0 = nt * BT;
     };
 
     // ---- LDS-DMA staging.  A stage = 16 pieces of 8 LDS rows x 128 B; this wave issues two of them.  Lane l of a piece
@@ -166,8 +169,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8w_bf16_k(NtArgsB p) {
                 stamps[((blockIdx.x * 8 + stamp_slot) * 2 + gm) * 6 + which] = __builtin_amdgcn_s_memtime();
         }
     };
-    int t = blockIdx.x * per_block;
-    if (t >= t_end) return;
+    int t = blockIdx.x;
+    if (t >= n_tiles) return;
     int64_t m0; int n0;
     tile_origin(t, m0, n0);
     __amdgpu_buffer_rsrc_t xc = rsrc_x(m0), wc = rsrc_w(n0), xn = xc, wnx = wc;
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8w_bf16_k(NtArgsB p) {
         if (gm == 1) wg_barrier();                          // waves 4-7 run one barrier behind waves 0-3
         stamp(1);
 
-        const int tn = t + 1;
+        const int tn = t + gridDim.x;
         int64_t mn = m0; int nn = n0;
         for (int it = 0; it < n_it; ++it) {
             // the K-tile pair staged from phase 3 on: the next pair of this tile, or the first pair of the next tile
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8w_bf16_k(NtArgsB p) {
             int kb_n = (2 * it + 2) * (2 * BK);             // byte offset of that pair's first K-tile within a row
             if (last_it) {
                 kb_n = 0;
-                more = tn < t_end;
+                more = tn < n_tiles;
                 if (more) { tile_origin(tn, mn, nn); xn = rsrc_x(mn); wnx = rsrc_w(nn); }
             }
             const int kb_c = (2 * it + 1) * (2 * BK);       // the current pair's second K-tile
@@ -377,7 +380,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8w_bf16_k(NtArgsB p) {
         stamp(4);
         ++stamp_slot;
         t = tn;
-        if (t >= t_end) break;
+        if (t >= n_tiles) break;
         m0 = mn; n0 = nn; xc = xn; wc = wnx;
     }
 }
