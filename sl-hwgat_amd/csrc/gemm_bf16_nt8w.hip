@@ -67,7 +67,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8w_bf16_k(NtArgsB p) {
     const int n_it = p.K / (2 * BK);                        // main-loop iterations per tile: two K-tiles each
     const int K2 = p.K * 2;                                 // bytes per matrix row
 
-    // ---- tile order: XCD-aware (the n-tiles of a 256-row block run on one XCD at the same time), see gemm_nt_k
+    // ---- tile order: XCD-aware (the n-tiles of a 256-row block run on one XCD at the same time), see gemm_nt_k.
+    // (Round 3 also tried contiguous runs -- one block takes all column tiles of a row block one after the other: the
+    // re-reads then MISS this XCD's L2, 32 CUs stream 8 MB per tile time through 4 MB: FETCH_SIZE x2 of the qkv launch
+    // 1 046 MB against 355 MB in this order and 168 MB algorithmic; same time, the misses land in the Infinity Cache.)
     const int swz_tiles = (row_blocks / 8) * 8 * tiles_n;
     auto tile_origin = [&](int t, int64_t& m0, int& n0) {
         int rb, nt;
