@@ -272,6 +272,13 @@ int hwgat_linear_nt_bf16_ex(const void* A, const void* W, const float* bias, voi
 int hwgat_linear_tn_bf16(const void* A, const void* B, float* dW, float* db, int64_t M, int N, int K,
                          uint32_t pro_seed, float pro_p, const float* mean, const float* rstd,
                          const float* gamma, const float* beta, void* stream);
+/* The same for plain operands (no dropout mask, no LayerNorm) with a caller-owned workspace of
+ * hwgat_linear_tn_bf16_ws_bytes(M, N, K) bytes: the partial dW tiles of the M slices are written as slabs and added in a
+ * FIXED order by a second launch (no global atomics: ~20 us less per launch at the HWGAT shapes, dW bit-reproducible).
+ * ws == NULL, too small, or a shape the slab kernel does not take (the query returns 0): hwgat_linear_tn_bf16. */
+int64_t hwgat_linear_tn_bf16_ws_bytes(int64_t M, int N, int K);
+int hwgat_linear_tn_bf16_ws(const void* A, const void* B, float* dW, float* db, int64_t M, int N, int K,
+                            float* ws, int64_t ws_bytes, void* stream);
 
 /* out[C,R] = in[R,C]^T (used on weights only) */
 int hwgat_transpose_f32(const float* in, float* out, int R, int C, void* stream);

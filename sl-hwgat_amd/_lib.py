@@ -51,6 +51,8 @@ _SIGS = {
     "hwgat_linear_tn_f32": [_P, _P, _P, _P, _L, _I, _I, _U, _F, _P, _P, _P, _P, _P],
     "hwgat_linear_nt_bf16": [_P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _P, _U, _F, _I, _P, _P, _P, _U, _F, _P],
     "hwgat_linear_tn_bf16": [_P, _P, _P, _P, _L, _I, _I, _U, _F, _P, _P, _P, _P, _P],
+    "hwgat_linear_tn_bf16_ws_bytes": [_L, _I, _I],
+    "hwgat_linear_tn_bf16_ws": [_P, _P, _P, _P, _L, _I, _I, _P, _L, _P],
     "hwgat_transpose_f32": [_P, _P, _I, _I, _P],
     "hwgat_dropout_mask_f32": [_P, _L, _U, _F, _P],
 }
@@ -61,7 +63,7 @@ def declared_symbols():
     """every function name declared in include/hwgat_hip.h"""
     with open(HEADER) as fh:
         src = re.sub(r"/\*.*?\*/", "", fh.read(), flags=re.S)
-    return sorted(set(re.findall(r"\bint\s+(hwgat_\w+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(?:int|int64_t)\s+(hwgat_\w+)\s*\(", src)))
 
 
 def header_abi_version():
@@ -98,7 +100,7 @@ def lib():
         for name, args in _SIGS.items():
             fn = getattr(handle, name)
             fn.argtypes = args
-            fn.restype = _I
+            fn.restype = _L if name.endswith("_ws_bytes") else _I
         have, want = handle.hwgat_abi_version(), header_abi_version()
         if have != want:
             raise RuntimeError(f"{LIB_PATH} reports ABI {have}, include/hwgat_hip.h declares {want}: rebuild the library")

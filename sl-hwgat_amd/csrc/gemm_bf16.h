@@ -75,7 +75,8 @@ int hwgat_launch_nt256_bf16(const NtArgsB& a, int pro, int epi, hipStream_t st);
 
 // defined in gemm_bf16_tn8w.hip: 256x256 dW tiles on eight waves with LDS-DMA operand streaming; plain operands only
 bool hwgat_tn8w_bf16_takes(int64_t M, int N, int K, float pro_p, const float* mean);
-int hwgat_launch_tn8w_bf16(TnArgsB a, hipStream_t st);
+int hwgat_launch_tn8w_bf16(TnArgsB a, hipStream_t st, float* ws = nullptr);   // ws: hwgat_tn8w_bf16_ws_floats() floats, or NULL (atomics)
+int64_t hwgat_tn8w_bf16_ws_floats(int64_t M, int N, int K);
 
 // defined in gemm_bf16_nt8w.hip: the same tile on eight waves with LDS-DMA operand streaming and a register epilogue;
 // M % 256 == N % 256 == K % 128 == 0, no A-side prologue (PRO_NONE / PRO_LN_FOLD)

@@ -622,6 +622,21 @@ extern "C" int hwgat_linear_nt_bf16(const void* A, const void* W, const float* b
                                    epi_seed, epi_p, nullptr, nullptr, 0, 0, stream);
 }
 
+extern "C" int64_t hwgat_linear_tn_bf16_ws_bytes(int64_t M, int N, int K) { return 4 * hwgat_tn8w_bf16_ws_floats(M, N, K); }
+
+// plain operands with a caller-owned workspace: the M-split partial tiles are combined by a fixed-order reduction instead of
+// global atomics (faster, and dW is bit-reproducible); shapes the slab kernel does not take, or a workspace that is too
+// small / NULL, fall back to hwgat_linear_tn_bf16 (atomics).  db always accumulates with atomics (N floats per block).
+extern "C" int hwgat_linear_tn_bf16_ws(const void* A, const void* B, float* dW, float* db, int64_t M, int N, int K,
+                                       float* ws, int64_t ws_bytes, void* stream) {
+    if (!A || !B || !dW || M <= 0 || N <= 0 || K <= 0) return HWGAT_EINVAL;
+    const int64_t need = hwgat_linear_tn_bf16_ws_bytes(M, N, K);
+    if (need == 0 || !ws || ws_bytes < need)
+        return hwgat_linear_tn_bf16(A, B, dW, db, M, N, K, 0, 0.f, nullptr, nullptr, nullptr, nullptr, stream);
+    TnArgsB a{(const bf16_t*)A, (const bf16_t*)B, dW, db, nullptr, nullptr, nullptr, nullptr, M, N, K, 1, M, 0, 0.f, 0};
+    return hwgat_launch_tn8w_bf16(a, (hipStream_t)stream, ws);
+}
+
 extern "C" int hwgat_linear_tn_bf16(const void* A, const void* B, float* dW, float* db, int64_t M, int N, int K,
                                     uint32_t pro_seed, float pro_p, const float* mean, const float* rstd,
                                     const float* gamma, const float* beta, void* stream) {

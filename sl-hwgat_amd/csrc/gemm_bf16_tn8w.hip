@@ -43,7 +43,12 @@ __device__ __forceinline__ void wg_barrier() {          // raw: no implicit vmcn
     __builtin_amdgcn_sched_barrier(0);
 }
 
-__global__ __launch_bounds__(512, 2) void gemm_tn8w_bf16_k(TnArgsB p) {
+// SLAB: the block's 256x256 fp32 tile goes to a workspace slab instead of global atomics, lane-linear (every store
+// instruction is 1 KiB contiguous): ws[((split * n_tiles + tile) * 8 + wave) * 32 + a * 4 + c][lane] = acc[a][c]; dw_reduce_k
+// adds the slabs of a tile in split order.  64 MB of memory-side atomics per launch (~49 us at the ~1.3 TB/s they sustain)
+// become 64 MB of streaming stores + 64 MB of streaming reads, and the sum's order is fixed: dW is bit-reproducible.
+template <bool SLAB>
+__global__ __launch_bounds__(512, 2) void gemm_tn8w_bf16_k(TnArgsB p, float* __restrict__ ws) {
     __shared__ __attribute__((aligned(16))) unsigned char smb[SMEM];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -191,13 +196,21 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8w_bf16_k(TnArgsB p) {
     if (gm == 0) wg_barrier();                              // matches the partner's last barrier (equal barrier counts)
 
     // ---- epilogue: acc[a][c][r] is dW[n0 + gm*128 + a*16 + fq*4 + r][k0 + wk*64 + c*16 + fr]
-    float* dst = p.dW + (int64_t)(n0 + gm * 128 + fq * 4) * p.K + k0 + wk * 64 + fr;
+    if constexpr (SLAB) {
+        float* slab = ws + ((((int64_t)split * n_tiles + tile) * 8 + wave) * 32) * 256 + lane * 4;
 #pragma unroll
-    for (int a = 0; a < 8; ++a)
+        for (int a = 0; a < 8; ++a)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+            for (int c = 0; c < 4; ++c) *reinterpret_cast<f32x4*>(slab + (a * 4 + c) * 256) = acc[a][c];
+    } else {
+        float* dst = p.dW + (int64_t)(n0 + gm * 128 + fq * 4) * p.K + k0 + wk * 64 + fr;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) atomicAdd(dst + (int64_t)(a * 16 + r) * p.K + c * 16, acc[a][c][r]);
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) atomicAdd(dst + (int64_t)(a * 16 + r) * p.K + c * 16, acc[a][c][r]);
+    }
     if (want_db) {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
@@ -209,13 +222,38 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8w_bf16_k(TnArgsB p) {
     }
 }
 
+// dW tile += the slabs of its M splits, in split order.  One thread per 16-byte slab slot: slot = ((wave*8 + a)*4 + c)*64 + lane.
+__global__ __launch_bounds__(256) void dw_reduce_k(const float* __restrict__ ws, float* __restrict__ dW, int n_split,
+                                                   int n_tiles, int tiles_k, int K) {
+    const int tile = blockIdx.x >> 6;
+    const int slot = (blockIdx.x & 63) * 256 + threadIdx.x;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    const float* src = ws + ((int64_t)tile * 16384 + slot) * 4;
+    for (int sp = 0; sp < n_split; ++sp) s += *reinterpret_cast<const f32x4*>(src + (int64_t)sp * n_tiles * 65536);
+    const int lane = slot & 63, c = (slot >> 6) & 3, a = (slot >> 8) & 7, wave = slot >> 11;
+    const int gm = wave >> 2, wk = wave & 3, fr = lane & 15, fq = lane >> 4;
+    const int n0 = (tile / tiles_k) * BT, k0 = (tile % tiles_k) * BT;
+    float* dst = dW + (int64_t)(n0 + gm * 128 + a * 16 + fq * 4) * K + k0 + wk * 64 + c * 16 + fr;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dst[(int64_t)r * K] += s[r];
+}
+
 }  // namespace
 
 bool hwgat_tn8w_bf16_takes(int64_t M, int N, int K, float pro_p, const float* mean) {
     return N % BT == 0 && K % BT == 0 && M % (2 * BM) == 0 && M >= 2 * BM && pro_p == 0.f && mean == nullptr;
 }
 
-int hwgat_launch_tn8w_bf16(TnArgsB a, hipStream_t st) {
+// floats of workspace the slab form needs for this shape (every block's 256x256 tile), 0 if the kernel does not take it
+int64_t hwgat_tn8w_bf16_ws_floats(int64_t M, int N, int K) {
+    if (!hwgat_tn8w_bf16_takes(M, N, K, 0.f, nullptr)) return 0;
+    const int n_tiles = (N / BT) * (K / BT);
+    int want = 256 / n_tiles / 8 * 8;
+    if (want < 8) want = 8;
+    return (int64_t)want * n_tiles * 65536;
+}
+
+int hwgat_launch_tn8w_bf16(TnArgsB a, hipStream_t st, float* ws) {
     if (!hwgat_tn8w_bf16_takes(a.M, a.N, a.K, a.pro_p, a.mean)) return HWGAT_ESHAPE;
     const int n_tiles = (a.N / BT) * (a.K / BT);
     // one round of equal blocks, one per CU: the split count a multiple of 8 (split s lives on XCD s % 8, the tiles of a
@@ -229,6 +267,11 @@ int hwgat_launch_tn8w_bf16(TnArgsB a, hipStream_t st) {
     a.n_split = (int)((its + per - 1) / per);
     if ((int64_t)a.rows_per_split * (a.N > a.K ? a.N : a.K) * 2 > 0x7fffffff) return HWGAT_ESHAPE;   // 32-bit DMA offsets within a slice
     const int grid = ((a.n_split + 7) / 8) * 8 * n_tiles;
-    gemm_tn8w_bf16_k<<<grid, 512, 0, st>>>(a);
+    if (ws) {
+        gemm_tn8w_bf16_k<true><<<grid, 512, 0, st>>>(a, ws);
+        dw_reduce_k<<<n_tiles * 64, 256, 0, st>>>(ws, a.dW, a.n_split, n_tiles, a.K / BT, a.K);
+    } else {
+        gemm_tn8w_bf16_k<false><<<grid, 512, 0, st>>>(a, nullptr);
+    }
     HWGAT_LAUNCH_CHECK();
 }
