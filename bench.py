@@ -348,8 +348,9 @@ def secondary_config3(hw, train_mod, dev, steps=10, warmup=3):
     for name in ("hwgat_linear_nt_bf16", "hwgat_linear_tn_bf16"):
         n, ms = timers.get(name, (0, 0.0))
         n2, ms2 = timers.get(name + "_ex", (0, 0.0))
-        if n + n2:
-            kern[name] = {"launches_per_step": (n + n2) // 2, "ms_per_step": round((ms + ms2) / 2, 3)}
+        n3, ms3 = timers.get(name + "_ws", (0, 0.0))
+        if n + n2 + n3:
+            kern[name] = {"launches_per_step": (n + n2 + n3) // 2, "ms_per_step": round((ms + ms2 + ms3) / 2, 3)}
     return {"value": round(rate, 2), "unit": "clips/s", "dtype": "bf16", "steps": steps, "warmup": warmup,
             "ms_per_step": round(elapsed / steps * 1e3, 3),
             "config": {"workload": f"BASELINE configs[2]: HWGAT train step (fwd+loss+bwd+AdamW), B={c['B']}/GPU T={c['T']} "
@@ -628,7 +629,8 @@ def main():
         for name, fl in (("hwgat_linear_nt_" + args.dtype, 2 * flops_fwd), ("hwgat_linear_tn_" + args.dtype, flops_fwd)):
             n, ms = timers.get(name, (0, 0.0))
             n2, ms2 = timers.pop(name + "_ex", (0, 0.0))          # the same linears with the statistics / merge epilogue
-            n, ms = n + n2, ms + ms2
+            n3, ms3 = timers.pop(name + "_ws", (0, 0.0))          # ... and the weight gradients with the workspace reduction
+            n, ms = n + n2 + n3, ms + ms2 + ms3
             if n:
                 ach = fl * n_timed / (ms * 1e-3)
                 kern[name] = {"bound": "mfma", "achieved": round(ach / 1e12, 1), "peak": peak / 1e12,
