@@ -25,24 +25,17 @@
 // dK / dV of a key frame collect the contributions of query frames f-1, f, f+1 in a sliding
 // 3-frame accumulator window and are stored once.
 #include <stdlib.h>
-#include "common.h"
+#include "band_common.h"
 
 namespace {
+using namespace band;
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
-
-struct BandGeom {
-    int F, K, nW, nH, d, seg, n_seg;      // seg = query frames per unit, n_seg = segments per clip
-};
 
 // D(16x16) += A(16x4) B(4x16): lane l supplies A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15];
 // register r of lane l is D[i = 4*(l>>4) + r][j = l&15].
 __device__ __forceinline__ f32x4v mfma16(float a, float b, f32x4v c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
-
-template <int HD> __device__ __forceinline__ constexpr float band_scale() {
-    return HD == 16 ? 0.25f : 0.17677669529663687f;            // float(head_dim ** -0.5), WGATE.py:79,92
 }
 
 template <typename T> __device__ __forceinline__ f32x4v ld4(const T* p) {
@@ -129,24 +122,6 @@ __device__ __forceinline__ void mul_cols(const f32x4v& a, const ColT<NC>& y, f32
         acc[ct] = mfma16(a.z, y.v[ct][2], acc[ct]);
         acc[ct] = mfma16(a.w, y.v[ct][3], acc[ct]);
     }
-}
-
-struct BandUnit {
-    int64_t tok0;          // token index of (clip, frame 0, first joint of the window)
-    int head, w, f0, f1;   // query frames [f0, f1)
-};
-__device__ __forceinline__ BandUnit decode_band(const BandGeom& g, int u) {
-    BandUnit r;
-    const int sgi = u % g.n_seg;
-    int t = u / g.n_seg;
-    r.head = t % g.nH;
-    t /= g.nH;
-    r.w = t % g.nW;
-    const int b = t / g.nW;
-    r.tok0 = (int64_t)b * g.F * g.K + r.w * 16;
-    r.f0 = sgi * g.seg;
-    r.f1 = min(g.F, r.f0 + g.seg);
-    return r;
 }
 
 // probabilities of one query row from its three key tiles; masked / out-of-clip entries are exactly 0
@@ -457,10 +432,6 @@ __global__ void mfma16_probe_k(const float* a, const float* b, float* out) {
     for (int i = 0; i < 4; ++i) out[lane * 4 + i] = acc[i];
 }
 
-bool band_ok(int B, int F, int nW, int nH, int hd) {
-    return B > 0 && F > 0 && nW > 0 && nH > 0 && (hd == 16 || hd == 32);
-}
-
 }  // namespace
 
 extern "C" int hwgat_debug_mfma16x16x4(const float* a, const float* b, float* out, void* stream) {
@@ -484,14 +455,18 @@ extern "C" int hwgat_band_attn_fwd(const void* qkv, void* o, const uint64_t* mas
     const int64_t units = base_units * n_seg;
     if (units > 0x7fffffff) return HWGAT_ESHAPE;
     hipStream_t st = (hipStream_t)stream;
+    // bf16 storage takes the bf16-MFMA kernels of band_attn_bf16.hip; the fp32-MFMA form on bf16 data survives as a lab A/B
+    static const bool old_b16 = lab_env("HWGAT_BAND_B16") && lab_env("HWGAT_BAND_B16")[0] == '0';
     const int blocks = (int)((units + 3) / 4);
     // prefetch depth / occupancy: A/B on MI355X at B64 T128 K64 (fp32): PF 8 at 2 waves/SIMD 327 us, PF 4 at 3-4 waves/SIMD 295-302 us
 #define FWD(T)                                                                                                  \
     if (hd == 32) band_attn_fwd_k<T, 32, 4, 1><<<blocks, 256, 0, st>>>((const T*)qkv, (T*)o, maskrows, g, (int)units); \
     else band_attn_fwd_k<T, 16, 4, 3><<<blocks, 256, 0, st>>>((const T*)qkv, (T*)o, maskrows, g, (int)units);
     if (dtype == HWGAT_F32) { FWD(float) }
-    else if (dtype == HWGAT_BF16) { FWD(bf16_t) }
-    else return HWGAT_EDTYPE;
+    else if (dtype == HWGAT_BF16) {
+        if (!old_b16) return hwgat_launch_band_fwd_b16(qkv, o, maskrows, B, F, nW, nH, hd, st);
+        FWD(bf16_t)
+    } else return HWGAT_EDTYPE;
 #undef FWD
     HWGAT_LAUNCH_CHECK();
 }
@@ -504,6 +479,7 @@ extern "C" int hwgat_band_attn_bwd(const void* qkv, const void* dO, void* dqkv, 
     const int64_t units = (int64_t)B * nW * nH;
     if (units > 0x7fffffff) return HWGAT_ESHAPE;
     hipStream_t st = (hipStream_t)stream;
+    static const bool old_b16 = lab_env("HWGAT_BAND_B16") && lab_env("HWGAT_BAND_B16")[0] == '0';
     const int blocks = (int)((units + 3) / 4);
     // register-only form: PF 2 at 1 wave/SIMD 644 us, PF 2 at 2-3 waves/SIMD 630 us, PF 1 at 2 waves/SIMD 619 us (all issue-bound
     // alike); with the LDS transposes (XPOSE, the default; HWGAT_BAND_XPOSE=0 selects the register-only form) 514 us
@@ -515,8 +491,10 @@ extern "C" int hwgat_band_attn_bwd(const void* qkv, const void* dO, void* dqkv, 
     else if (xpose) band_attn_bwd_k<T, 16, 2, 2, true><<<blocks, 256, 0, st>>>(BWD_ARGS(T));         \
     else band_attn_bwd_k<T, 16, 2, 2, false><<<blocks, 256, 0, st>>>(BWD_ARGS(T));
     if (dtype == HWGAT_F32) { BWD(float) }
-    else if (dtype == HWGAT_BF16) { BWD(bf16_t) }
-    else return HWGAT_EDTYPE;
+    else if (dtype == HWGAT_BF16) {
+        if (!old_b16) return hwgat_launch_band_bwd_b16(qkv, dO, dqkv, maskrows, B, F, nW, nH, hd, st);
+        BWD(bf16_t)
+    } else return HWGAT_EDTYPE;
 #undef BWD
 #undef BWD_ARGS
     HWGAT_LAUNCH_CHECK();

@@ -1,0 +1,472 @@
+// Fused band graph-attention for the WGATE sibling model, bf16 storage, on gfx950 (MI355X).
+//
+// Same contract as band_attn.hip (MSA.forward's attention core of the reference's hwgat/models/WGATE.py:87-108 with
+// window_partition / window_reverse, WGATE.py:32-65, folded into index arithmetic; block-tridiagonal 0 / -10000 mask of
+// model_params.py:209-228 as 48-bit rows), but every product runs on v_mfma_f32_16x16x16_bf16 instead of four
+// v_mfma_f32_16x16x4_f32, and nothing is converted to fp32 on the way in:
+//
+//   unit = (clip, part window, frame segment, head): ONE wavefront walks the frames of its segment in order; the four
+//          waves of a workgroup are four neighbouring heads (their 32-byte row pieces share 128-byte lines).
+//   row operand  X[row = l&15][16 ch + 4 (l>>4) + 0..3]: one 8-byte global load per lane and 16 channels, used as it
+//          comes as the A or B operand of a head-dim contraction (S^T = K Q^T, dP^T = V dO^T).
+//   column operand X[row = 4 (l>>4) + 0..3][16 ct + (l&15)]: the A operand of every contraction over tokens
+//          (O^T = V^T P^T, dQ^T = K^T dS^T, dK^T = Q^T dS, dV^T = dO^T P).  It is made from the row operand by one
+//          8-byte write into a wave-private 16 x 16 LDS tile and one ds_read_b64_tr_b16: no second, element-wise global
+//          load of the same data as in the fp32 kernel.
+//   results come out of the MFMA as [channel 4g + r][token l&15] = four consecutive channels of one token per lane: one
+//          8-byte store per lane and 16 channels for o, dq, dk, dv.
+//   softmax in fp32 registers (base-2 exponent, visibility as an additive 0 / -inf bias, cross-lane steps with
+//          v_permlane16/32_swap); P and dS are rounded to bf16 as MFMA operands (what a bf16 matmul of the reference
+//          does with them); scores are scaled in fp32 AFTER the product, so q is not rounded a second time.
+//   backward: P / dS transposed through LDS tiles like the column operands; the clip is cut into frame segments with a
+//          one-query-frame halo on either side (recomputed, not stored) so that the grid reaches >= 4 waves per SIMD.
+//
+// HBM traffic stays the algorithmic 4 E s (fwd) / 7 E s (bwd) plus the segment halos.
+#include <stdlib.h>
+#include "band_common.h"
+
+namespace {
+using namespace band;
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+typedef __attribute__((address_space(3))) u32x2v lds_u32x2;
+
+constexpr int TROW = 40;                 // bytes per row of a transposing tile: 16 bf16 + 8 pad (8-byte aligned rows)
+constexpr int TTILE = 16 * TROW;         // one 16 x 16 tile
+constexpr float NEG_INF = -__builtin_inff();
+
+// D(16x16) += A(16x16) B(16x16): lane l supplies A[i = l&15][k = 4 (l>>4) + e] and B[k = 4 (l>>4) + e][j = l&15], e = 0..3;
+// register r of lane l is D[i = 4 (l>>4) + r][j = l&15].
+// (operands travel as two dwords = 4 packed bf16: a bf16x4 bit-cast at the MFMA makes the compiler convert one value
+// per instruction and merge with v_perm)
+typedef u32x2v pk4;
+__device__ __forceinline__ f32x4v mfma_bf(pk4 a, pk4 b, f32x4v c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ uint32_t pk2(float a, float b) {           // round to nearest even, v_cvt_pk_bf16_f32
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, bf16x2));
+}
+__device__ __forceinline__ pk4 to_bf(const f32x4v& v) { return pk4{pk2(v.x, v.y), pk2(v.z, v.w)}; }
+
+// reductions over the 4 lanes l, l^16, l^32, l^48 without LDS
+__device__ __forceinline__ float xg_max(float v) {
+    u32x2v r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __builtin_fmaxf(__uint_as_float(r.x), __uint_as_float(r.y));
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __builtin_fmaxf(__uint_as_float(r.x), __uint_as_float(r.y));
+}
+__device__ __forceinline__ float xg_sum(float v) {
+    u32x2v r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r.x) + __uint_as_float(r.y);
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+
+template <int NC> struct Row16 { pk4 c[NC]; };     // X[row = l&15][16 ch + 4 g + e]
+template <int NC> struct Col16 { pk4 v[NC]; };     // X[row = 4 g + e][16 ct + (l&15)]
+
+// `base` is wave-uniform, `off` a 32-bit per-lane element offset (scalar base + vector offset addressing)
+template <int NC> __device__ __forceinline__ Row16<NC> load_row16(const bf16_t* base, uint32_t off) {
+    Row16<NC> t;
+#pragma unroll
+    for (int ch = 0; ch < NC; ++ch) t.c[ch] = *reinterpret_cast<const pk4*>(base + off + 16 * ch);
+    return t;
+}
+template <int NC> __device__ __forceinline__ Row16<NC> zero_row16() {
+    Row16<NC> t;
+#pragma unroll
+    for (int ch = 0; ch < NC; ++ch) t.c[ch] = pk4{0u, 0u};
+    return t;
+}
+
+// D[i][j] = sum_c X[i][c] Y[j][c] of two row operands: lane (j = l&15, g), register r -> D[4g + r][j]
+template <int NC> __device__ __forceinline__ f32x4v dot_rows16(const Row16<NC>& x, const Row16<NC>& y) {
+    f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ch = 0; ch < NC; ++ch) acc = mfma_bf(x.c[ch], y.c[ch], acc);
+    return acc;
+}
+// acc[ct][r] (lane j) += sum_k Y[k][16 ct + 4g + r] a[j][k]: Y a column operand over the 16 tokens k, a[e] = A[j = l&15][k = 4g + e]
+template <int NC> __device__ __forceinline__ void mul_cols16(const Col16<NC>& y, pk4 a, f32x4v (&acc)[NC]) {
+#pragma unroll
+    for (int ct = 0; ct < NC; ++ct) acc[ct] = mfma_bf(y.v[ct], a, acc[ct]);
+}
+
+// wave-private transposing tile: lane (row = l&15, g) writes its 4 elements of columns 4g .. 4g+3; lane (col = l&15, g)
+// reads back the elements of rows 4g .. 4g+3 of its column (ds_read_b64_tr_b16: 16-lane group g takes the 4 x 16 block of
+// rows 4g .. 4g+3; lane 4q + p of the group supplies the address of row 4g + q, columns 4p .. 4p+3)
+struct TileXpose {
+    uint32_t put, get;
+    __device__ __forceinline__ TileXpose(int lane) {
+        const int lr = lane & 15, g = lane >> 4;
+        put = lr * TROW + g * 8;
+        get = (4 * g + (lr >> 2)) * TROW + (lr & 3) * 8;
+    }
+    __device__ __forceinline__ void write(char* tile, pk4 v) const { *(lds_u32x2*)(tile + put) = v; }
+    __device__ __forceinline__ pk4 read(char* tile) const {
+        return __builtin_bit_cast(pk4, __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + get)));
+    }
+};
+__device__ __forceinline__ void wave_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+template <int NC> __device__ __forceinline__ Col16<NC> to_col(const TileXpose& x, char* tiles, const Row16<NC>& r) {
+    Col16<NC> c;
+#pragma unroll
+    for (int ch = 0; ch < NC; ++ch) x.write(tiles + ch * TTILE, r.c[ch]);
+    wave_fence();
+#pragma unroll
+    for (int ch = 0; ch < NC; ++ch) c.v[ch] = x.read(tiles + ch * TTILE);
+    wave_fence();
+    return c;
+}
+
+// unit = ((clip, window), segment, head), head fastest: the 4 waves of a workgroup are neighbouring heads of one segment
+struct Unit16 {
+    int64_t tok0;          // token index of (clip, frame 0, first joint of the window)
+    int head, w, f0, f1;   // owned frames [f0, f1)
+};
+__device__ __forceinline__ Unit16 decode16(const BandGeom& g, int u) {
+    Unit16 r;
+    r.head = u % g.nH;
+    int t = u / g.nH;
+    const int sgi = t % g.n_seg;
+    t /= g.n_seg;
+    r.w = t % g.nW;
+    const int b = t / g.nW;
+    r.tok0 = (int64_t)b * g.F * g.K + r.w * 16;
+    r.f0 = sgi * g.seg;
+    r.f1 = min(g.F, r.f0 + g.seg);
+    return r;
+}
+
+// additive visibility of the 3 x 4 keys (tile t, joint 4g + r) this lane holds for query joint l&15: 0 or -inf
+__device__ __forceinline__ void band_bias(uint64_t mrow, int g, float (&bias)[3][4]) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias[t][r] = ((mrow >> (16 * t + 4 * g + r)) & 1ull) ? 0.f : NEG_INF;
+}
+
+// e[t][r] = exp(scale s - max) over the visible keys of one query row (invisible / out-of-clip keys: exactly 0, as
+// exp(s - 10000 - max) is in the reference's fp32 softmax, WGATE.py:97-103); returns 1 / sum
+template <int HD>
+__device__ __forceinline__ float band_exp(const f32x4v (&s)[3], const float (&bias)[3][4], bool has_prev, bool has_next,
+                                          f32x4v (&e)[3]) {
+    constexpr float c1 = band_scale<HD>() * 1.4426950408889634f;        // scale * log2(e)
+    const float edge[3] = {has_prev ? 0.f : NEG_INF, 0.f, has_next ? 0.f : NEG_INF};
+    float m = NEG_INF;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float x = __builtin_fmaf(s[t][r], c1, bias[t][r]);
+            if (t != 1) x += edge[t];
+            e[t][r] = x;
+            m = __builtin_fmaxf(m, x);
+        }
+    m = xg_max(m);                                                       // the diagonal is always visible: m is finite
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            e[t][r] = __builtin_amdgcn_exp2f(e[t][r] - m);
+            sum += e[t][r];
+        }
+    return __builtin_amdgcn_rcpf(xg_sum(sum));
+}
+
+// =============================================================== forward
+template <int HD, int PF, int MINW>
+__global__ __launch_bounds__(256, MINW) void band_fwd_b16_k(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
+                                                            const uint64_t* __restrict__ maskrows, BandGeom g,
+                                                            int n_units) {
+    constexpr int NC = HD / 16;
+    __shared__ __attribute__((aligned(16))) char sm[4 * NC * TTILE];
+    const int lane = threadIdx.x & 63, lr = lane & 15, gq = lane >> 4;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    char* vt = sm + wib * (NC * TTILE);
+    const TileXpose xp(lane);
+    const int u_raw = blockIdx.x * 4 + wib;
+    const bool live = u_raw < n_units;                           // tail waves shadow the last unit (no stores): every
+    const int u = live ? u_raw : n_units - 1;                    // wave of a workgroup reaches the per-group barrier
+    const Unit16 un = decode16(g, u);
+    const int64_t rs = 3 * (int64_t)g.d;                         // qkv row stride (elements)
+    const bf16_t* qb = qkv + un.tok0 * rs + un.head * HD;
+    bf16_t* ob = o + un.tok0 * (int64_t)g.d + un.head * HD;
+    const int64_t fs = (int64_t)g.K * rs;                        // frame stride in qkv
+    const uint32_t roff = lr * (uint32_t)rs + 4 * gq;            // per-lane offsets in qkv ...
+    const uint32_t ooff = lr * (uint32_t)g.d + 4 * gq;           // ... and in o
+    float bias[3][4];
+    band_bias(maskrows[un.w * 16 + lr], gq, bias);
+
+    // sliding window: K (row operand) and V (column operand) of frames f-1, f, f+1
+    Row16<NC> kw[3];
+    Col16<NC> vw[3];
+    kw[0] = zero_row16<NC>();
+    {
+        const int fp = max(un.f0 - 1, 0);                        // frame 0 stands in when there is none: masked by `edge`
+        const Row16<NC> vp = load_row16<NC>(qb + fp * fs + 2 * g.d, roff);
+        if (un.f0 > 0) kw[0] = load_row16<NC>(qb + fp * fs + g.d, roff);
+        vw[0] = to_col<NC>(xp, vt, vp);
+        kw[1] = load_row16<NC>(qb + un.f0 * fs + g.d, roff);
+        vw[1] = to_col<NC>(xp, vt, load_row16<NC>(qb + un.f0 * fs + 2 * g.d, roff));
+    }
+
+    // prefetch ring: slot i holds Q of frame f+i and K, V of frame f+i+1
+    Row16<NC> rq[PF], rk[PF], rv[PF];
+    // loads are unconditional (a branch around a load makes the compiler drain the whole ring): frames past the clip
+    // re-read the last frame; such tiles are either never consumed or masked out
+    auto fill = [&](int i, int f) {                              // f = query frame of the slot
+        const int fq = min(f, g.F - 1), fk = min(f + 1, g.F - 1);
+        rq[i] = load_row16<NC>(qb + fq * fs, roff);
+        rk[i] = load_row16<NC>(qb + fk * fs + g.d, roff);
+        rv[i] = load_row16<NC>(qb + fk * fs + 2 * g.d, roff);
+    };
+#pragma unroll
+    for (int i = 0; i < PF; ++i) fill(i, un.f0 + i);
+
+    for (int fb = un.f0; fb < un.f0 + g.seg; fb += PF) {
+        // neighbouring heads stay within PF frames of each other: the line they share is touched while still cached
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int f = fb + i;
+            const Row16<NC> q = rq[i];
+            kw[2] = rk[i];
+            vw[2] = to_col<NC>(xp, vt, rv[i]);                   // outside the branch: the transposed read wants all lanes
+            fill(i, f + PF);
+            if (f < un.f1 && live) {
+                f32x4v s[3], e[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) s[t] = dot_rows16<NC>(kw[t], q);   // s[t][r] = S[q = lr][key = 4g + r]
+                const float inv = band_exp<HD>(s, bias, f > 0, f + 1 < g.F, e);
+                f32x4v oacc[NC];
+#pragma unroll
+                for (int ct = 0; ct < NC; ++ct) oacc[ct] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int t = 0; t < 3; ++t) mul_cols16<NC>(vw[t], to_bf(e[t]), oacc);
+                // lane (q = lr, g), reg r -> O[q][16 ct + 4g + r]; the row's 1 / sum is in this very lane
+                bf16_t* of = ob + (int64_t)f * g.K * g.d;
+#pragma unroll
+                for (int ct = 0; ct < NC; ++ct)
+                    *reinterpret_cast<pk4*>(of + ooff + 16 * ct) = to_bf(oacc[ct] * inv);
+            }
+            kw[0] = kw[1]; kw[1] = kw[2];
+            vw[0] = vw[1]; vw[1] = vw[2];
+        }
+    }
+}
+
+// =============================================================== backward
+// Unit = key frames [f0, f1) of one (clip, window, head): it walks the query frames f0-1 .. f1 (the two outer ones are
+// the halo: their softmax is recomputed in full, only their contribution to the owned key frames is kept), stores dq of
+// the query frames [f0, f1) and dk, dv of the key frames [f0, f1).
+template <int HD, int PF, int MINW>
+__global__ __launch_bounds__(256, MINW) void band_bwd_b16_k(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
+                                                            bf16_t* __restrict__ dqkv,
+                                                            const uint64_t* __restrict__ maskrows, BandGeom g,
+                                                            int n_units) {
+    constexpr int NC = HD / 16;
+    constexpr int NT = 3 * NC + 6;                               // tiles per wave: Q^T, dO^T, K^T chunks | P x 3 | dS x 3
+    __shared__ __attribute__((aligned(16))) char sm[4 * NT * TTILE];
+    const int lane = threadIdx.x & 63, lr = lane & 15, gq = lane >> 4;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    char* tq = sm + wib * (NT * TTILE);
+    char* tg = tq + NC * TTILE;
+    char* tk = tg + NC * TTILE;
+    char* tp = tk + NC * TTILE;
+    char* td = tp + 3 * TTILE;
+    const TileXpose xp(lane);
+    const int u_raw = blockIdx.x * 4 + wib;
+    const bool live = u_raw < n_units;                           // tail waves shadow the last unit without storing
+    const int u = live ? u_raw : n_units - 1;
+    const Unit16 un = decode16(g, u);
+    const int64_t rs = 3 * (int64_t)g.d;
+    const int64_t fs = (int64_t)g.K * rs, gs = (int64_t)g.K * g.d;
+    const bf16_t* qb = qkv + un.tok0 * rs + un.head * HD;
+    const bf16_t* gb = dO + un.tok0 * (int64_t)g.d + un.head * HD;
+    bf16_t* db = dqkv + un.tok0 * rs + un.head * HD;
+    const uint32_t roff = lr * (uint32_t)rs + 4 * gq;            // lane offsets in qkv / dqkv ...
+    const uint32_t groff = lr * (uint32_t)g.d + 4 * gq;          // ... and in dO
+    float bias[3][4];
+    band_bias(maskrows[un.w * 16 + lr], gq, bias);
+    const int fa = max(un.f0 - 1, 0), fz = min(un.f1, g.F - 1);  // query frames fa .. fz (inclusive)
+
+    struct KeyFrame { Row16<NC> k, v; Col16<NC> kc; };
+    KeyFrame kw[3];
+    {
+        const int fp = max(fa - 1, 0);
+        kw[0].k = zero_row16<NC>();
+        kw[0].v = zero_row16<NC>();
+        if (fa > 0) {
+            kw[0].k = load_row16<NC>(qb + fp * fs + g.d, roff);
+            kw[0].v = load_row16<NC>(qb + fp * fs + 2 * g.d, roff);
+        }
+        kw[0].kc = to_col<NC>(xp, tk, kw[0].k);
+        kw[1].k = load_row16<NC>(qb + fa * fs + g.d, roff);
+        kw[1].v = load_row16<NC>(qb + fa * fs + 2 * g.d, roff);
+        kw[1].kc = to_col<NC>(xp, tk, kw[1].k);
+    }
+    f32x4v dk[3][NC], dv[3][NC];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int ct = 0; ct < NC; ++ct) { dk[t][ct] = f32x4v{0.f, 0.f, 0.f, 0.f}; dv[t][ct] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
+
+    // prefetch ring: slot i = query frame f+i: Q, dO and K, V of key frame f+i+1 (all as row operands)
+    struct Slot { Row16<NC> q, go, k, v; };
+    Slot ring[PF];
+    auto fill = [&](int i, int f) {                              // unconditional, clamped (see the forward kernel)
+        const int fq = min(f, g.F - 1), fk = min(f + 1, g.F - 1);
+        ring[i].q = load_row16<NC>(qb + fq * fs, roff);
+        ring[i].go = load_row16<NC>(gb + fq * gs, groff);
+        ring[i].k = load_row16<NC>(qb + fk * fs + g.d, roff);
+        ring[i].v = load_row16<NC>(qb + fk * fs + 2 * g.d, roff);
+    };
+#pragma unroll
+    for (int i = 0; i < PF; ++i) fill(i, fa + i);
+
+    auto store_key = [&](int f, const f32x4v (&k)[NC], const f32x4v (&v)[NC]) {
+        bf16_t* row = db + f * fs + roff;                        // lane (key = lr, g), reg r -> [key][16 ct + 4g + r]
+#pragma unroll
+        for (int ct = 0; ct < NC; ++ct) {
+            *reinterpret_cast<pk4*>(row + g.d + 16 * ct) = to_bf(k[ct] * band_scale<HD>());
+            *reinterpret_cast<pk4*>(row + 2 * g.d + 16 * ct) = to_bf(v[ct]);
+        }
+    };
+
+    // every unit runs the same number of rounds (seg + 2 query frames at most): the workgroup barrier below is uniform
+    for (int it = 0; it < g.seg + 2; it += PF) {
+        __syncthreads();                                         // neighbouring heads stay within PF frames (see forward)
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int f = fa + it + i;
+            const Row16<NC> q = ring[i].q, go = ring[i].go;
+            kw[2].k = ring[i].k;
+            kw[2].v = ring[i].v;
+            fill(i, f + PF);
+            // column forms of this frame's Q, dO and of the new key frame (all lanes, outside the branch)
+#pragma unroll
+            for (int ch = 0; ch < NC; ++ch) {
+                xp.write(tq + ch * TTILE, q.c[ch]);
+                xp.write(tg + ch * TTILE, go.c[ch]);
+                xp.write(tk + ch * TTILE, kw[2].k.c[ch]);
+            }
+            wave_fence();
+            Col16<NC> qc, gc;
+#pragma unroll
+            for (int ch = 0; ch < NC; ++ch) {
+                qc.v[ch] = xp.read(tq + ch * TTILE);
+                gc.v[ch] = xp.read(tg + ch * TTILE);
+                kw[2].kc.v[ch] = xp.read(tk + ch * TTILE);
+            }
+            wave_fence();
+            if (f <= fz && live) {
+                const bool hp = f > 0, hn = f + 1 < g.F;
+                // ---- lane = query joint lr, registers = key joints 4g + r
+                f32x4v s[3], p[3], ds[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) s[t] = dot_rows16<NC>(kw[t].k, q);
+                const float inv = band_exp<HD>(s, bias, hp, hn, p);
+                float delta = 0.f;
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    p[t] *= inv;
+                    ds[t] = dot_rows16<NC>(kw[t].v, go);                       // dP[q = lr][key = 4g + r]
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) delta = __builtin_fmaf(p[t][r], ds[t][r], delta);
+                }
+                delta = xg_sum(delta);
+                pk4 pb[3], dsb[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    ds[t] = p[t] * (ds[t] - delta);                            // dS (the score scale goes on dq / dk)
+                    pb[t] = to_bf(p[t]);
+                    dsb[t] = to_bf(ds[t]);
+                    xp.write(tp + t * TTILE, pb[t]);
+                    xp.write(td + t * TTILE, dsb[t]);
+                }
+                // dQ[q = lr][16 ct + 4g + r] = scale * sum_key dS[q][key] K[key][c]
+                if (f >= un.f0 && f < un.f1) {
+                    f32x4v acc[NC];
+#pragma unroll
+                    for (int ct = 0; ct < NC; ++ct) acc[ct] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) mul_cols16<NC>(kw[t].kc, dsb[t], acc);
+                    bf16_t* row = db + f * fs + roff;
+#pragma unroll
+                    for (int ct = 0; ct < NC; ++ct)
+                        *reinterpret_cast<pk4*>(row + 16 * ct) = to_bf(acc[ct] * band_scale<HD>());
+                }
+                // ---- lane = key joint lr, registers = query joints 4g + r
+                wave_fence();
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const pk4 p2 = xp.read(tp + t * TTILE), ds2 = xp.read(td + t * TTILE);
+                    mul_cols16<NC>(qc, ds2, dk[t]);                            // dK[key][c] += sum_q dS[q][key] Q[q][c]
+                    mul_cols16<NC>(gc, p2, dv[t]);                             // dV[key][c] += sum_q P[q][key] dO[q][c]
+                }
+                wave_fence();
+                // key frame f-1 has now seen query frames f-2, f-1, f: done
+                if (hp && f - 1 >= un.f0) store_key(f - 1, dk[0], dv[0]);      // (f - 1 < f1 always: f <= f1)
+#pragma unroll
+                for (int ct = 0; ct < NC; ++ct) {
+                    dk[0][ct] = dk[1][ct]; dk[1][ct] = dk[2][ct]; dk[2][ct] = f32x4v{0.f, 0.f, 0.f, 0.f};
+                    dv[0][ct] = dv[1][ct]; dv[1][ct] = dv[2][ct]; dv[2][ct] = f32x4v{0.f, 0.f, 0.f, 0.f};
+                }
+                kw[0] = kw[1]; kw[1] = kw[2];
+            }
+        }
+    }
+    // the clip's last key frame has no query frame after it: after the rotation it sits in slot 0
+    if (live && un.f1 == g.F) store_key(g.F - 1, dk[0], dv[0]);
+}
+
+// frame segments per clip so that the grid holds `want` wavefronts; segments of at least `min_seg` frames
+int segments(int64_t base_units, int F, int64_t want, int min_seg, const char* lab_name) {
+    int n_seg = 1;
+    while (base_units * n_seg < want && F / (n_seg * 2) >= min_seg) n_seg *= 2;
+    if (const char* e = lab_env(lab_name)) n_seg = max(1, atoi(e));
+    return n_seg;
+}
+
+}  // namespace
+
+int hwgat_launch_band_fwd_b16(const void* qkv, void* o, const uint64_t* maskrows, int B, int F, int nW, int nH, int hd,
+                              hipStream_t st) {
+    const int64_t base_units = (int64_t)B * nW * nH;
+    int n_seg = segments(base_units, F, 256 * 4 * 4, 16, "HWGAT_BAND_FSEG");
+    const int seg = (F + n_seg - 1) / n_seg;
+    n_seg = (F + seg - 1) / seg;
+    BandGeom g{F, nW * 16, nW, nH, nH * hd, seg, n_seg};
+    const int64_t units = base_units * n_seg;
+    if (units > 0x7fffffff) return HWGAT_ESHAPE;
+    const int blocks = (int)((units + 3) / 4);
+    const bf16_t* x = (const bf16_t*)qkv;
+    if (hd == 32) band_fwd_b16_k<32, 4, 2><<<blocks, 256, 0, st>>>(x, (bf16_t*)o, maskrows, g, (int)units);
+    else band_fwd_b16_k<16, 4, 4><<<blocks, 256, 0, st>>>(x, (bf16_t*)o, maskrows, g, (int)units);
+    HWGAT_LAUNCH_CHECK();
+}
+
+int hwgat_launch_band_bwd_b16(const void* qkv, const void* dO, void* dqkv, const uint64_t* maskrows, int B, int F, int nW,
+                              int nH, int hd, hipStream_t st) {
+    const int64_t base_units = (int64_t)B * nW * nH;
+    int n_seg = segments(base_units, F, 256 * 4 * 3, 16, "HWGAT_BAND_BSEG");
+    const int seg = (F + n_seg - 1) / n_seg;
+    n_seg = (F + seg - 1) / seg;
+    BandGeom g{F, nW * 16, nW, nH, nH * hd, seg, n_seg};
+    const int64_t units = base_units * n_seg;
+    if (units > 0x7fffffff) return HWGAT_ESHAPE;
+    const int blocks = (int)((units + 3) / 4);
+    const bf16_t* x = (const bf16_t*)qkv;
+    if (hd == 32) band_bwd_b16_k<32, 1, 2><<<blocks, 256, 0, st>>>(x, (const bf16_t*)dO, (bf16_t*)dqkv, maskrows, g, (int)units);
+    else band_bwd_b16_k<16, 1, 3><<<blocks, 256, 0, st>>>(x, (const bf16_t*)dO, (bf16_t*)dqkv, maskrows, g, (int)units);
+    HWGAT_LAUNCH_CHECK();
+}

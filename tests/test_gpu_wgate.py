@@ -101,6 +101,15 @@ def test_band_attention_general_blocks_and_rejections():
     out.backward(do.to(DEV))
     assert rel_err(out.detach().cpu(), ref.detach()) < F32_TOL
     assert rel_err(x.grad.cpu(), ref_in.grad) < F32_TOL
+    # bf16 storage = the bf16-MFMA kernels (band_attn_bf16.hip): same masks, bf16-representable inputs
+    xb = qkv.to(DEV, torch.bfloat16).requires_grad_(True)
+    refb_in = xb.detach().cpu().double().requires_grad_(True)
+    refb = _oracle_attn(refb_in, adj, nH)
+    refb.backward(do.double())
+    outb = HF.band_attention(xb, rows, nH)
+    outb.backward(do.to(DEV, torch.bfloat16))
+    assert rel_err(outb.detach().float().cpu(), refb.detach()) < BF16_TOL / 2
+    assert rel_err(xb.grad.float().cpu(), refb_in.grad) < BF16_TOL / 2
     bad = adj.clone()
     bad[0, 0, 5 * 16 + 3] = 1                      # frame 0 sees frame 5
     with pytest.raises(NotImplementedError):
@@ -145,6 +154,39 @@ def test_full_size_properties():
     g2 = torch.randn(B, F, K, d, device=DEV, generator=g)
     HF.band_attention(x, rows, nH).backward(g2)
     assert x.grad[..., :d].abs().max() < 1e-3
+
+
+def test_full_size_properties_bf16():
+    """the bf16-MFMA kernels at the headline batch: properties that do not depend on the size, and independence of the
+    frame segmentation (forward and backward cut the clip into segments by grid size; halo frames are recomputed)"""
+    B, F, nW, nH, hd = 64, 128, 4, 8, 16
+    d, K = nH * hd, nW * 16
+    g = torch.Generator(device=DEV).manual_seed(1)
+    qkv = torch.randn(B, F, K, 3 * d, device=DEV, generator=g).to(torch.bfloat16)
+    do = torch.randn(B, F, K, d, device=DEV, generator=g).to(torch.bfloat16)
+    rows = HF.band_mask_rows(OW.band_adjacency(F, nW), F).to(DEV)
+    q1 = qkv.clone()
+    q1[..., 2 * d:] = 1.0
+    assert (HF.band_attention(q1, rows, nH).float() - 1).abs().max() < 2e-2          # rows of P (rounded to bf16) sum to 1
+    x = qkv.clone().requires_grad_(True)
+    a = HF.band_attention(x, rows, nH)
+    a.backward(do)
+    perm = torch.randperm(B, device=DEV)
+    xp = qkv[perm].contiguous().requires_grad_(True)
+    ap = HF.band_attention(xp, rows, nH)
+    ap.backward(do[perm].contiguous())
+    assert torch.equal(ap, a[perm]) and torch.equal(xp.grad, x.grad[perm])
+    # one clip alone runs with more, shorter segments: same bits, forward and backward
+    x1 = qkv[5:6].contiguous().requires_grad_(True)
+    a1 = HF.band_attention(x1, rows, nH)
+    a1.backward(do[5:6].contiguous())
+    assert torch.equal(a1, a[5:6]) and torch.equal(x1.grad, x.grad[5:6])
+    # one window of one clip against the dense fp64 oracle, forward and backward
+    ref_in = qkv[7:8, :, :16].cpu().double().requires_grad_(True)
+    ref = _oracle_attn(ref_in, OW.band_adjacency(F, 1), nH)
+    ref.backward(do[7:8, :, :16].cpu().double())
+    assert rel_err(a[7:8, :, :16].float().cpu(), ref.detach()) < BF16_TOL / 2
+    assert rel_err(x.grad[7:8, :, :16].float().cpu(), ref_in.grad) < BF16_TOL / 2
 
 
 # ------------------------------------------------------------------------------------------ whole model
