@@ -183,7 +183,9 @@ __device__ __forceinline__ float band_exp(const f32x4v (&s)[3], const float (&bi
 }
 
 // =============================================================== forward
-template <int HD, int PF, int MINW>
+// DBG (kernel lab only): 1 = memory only (loads, transposes, stores; no products, no softmax), 2 = products without the
+// softmax, 3 = no loads inside the frame loop
+template <int HD, int PF, int MINW, int DBG = 0>
 __global__ __launch_bounds__(256, MINW) void band_fwd_b16_k(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
                                                             const uint64_t* __restrict__ maskrows, BandGeom g,
                                                             int n_units) {
@@ -241,8 +243,198 @@ __global__ __launch_bounds__(256, MINW) void band_fwd_b16_k(const bf16_t* __rest
             const Row16<NC> q = rq[i];
             kw[2] = rk[i];
             vw[2] = to_col<NC>(xp, vt, rv[i]);                   // outside the branch: the transposed read wants all lanes
-            fill(i, f + PF);
-            if (f < un.f1 && live) {
+            if (DBG != 3) fill(i, f + PF);
+            if (DBG == 1) {
+                if (f < un.f1 && live) {
+                    bf16_t* of = ob + (int64_t)f * g.K * g.d;
+#pragma unroll
+                    for (int ct = 0; ct < NC; ++ct) *reinterpret_cast<pk4*>(of + ooff + 16 * ct) = q.c[ct] ^ kw[2].c[ct] ^ vw[2].v[ct];
+                }
+            } else if (f < un.f1 && live) {
+                f32x4v s[3], e[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) s[t] = dot_rows16<NC>(kw[t], q);   // s[t][r] = S[q = lr][key = 4g + r]
+                float inv = 1.f;
+                if (DBG == 2) { e[0] = s[0]; e[1] = s[1]; e[2] = s[2]; }
+                else inv = band_exp<HD>(s, bias, f > 0, f + 1 < g.F, e);
+                f32x4v oacc[NC];
+#pragma unroll
+                for (int ct = 0; ct < NC; ++ct) oacc[ct] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int t = 0; t < 3; ++t) mul_cols16<NC>(vw[t], to_bf(e[t]), oacc);
+                // lane (q = lr, g), reg r -> O[q][16 ct + 4g + r]; the row's 1 / sum is in this very lane
+                bf16_t* of = ob + (int64_t)f * g.K * g.d;
+#pragma unroll
+                for (int ct = 0; ct < NC; ++ct)
+                    *reinterpret_cast<pk4*>(of + ooff + 16 * ct) = to_bf(oacc[ct] * inv);
+            }
+            kw[0] = kw[1]; kw[1] = kw[2];
+            vw[0] = vw[1]; vw[1] = vw[2];
+        }
+    }
+}
+
+// ------------------------------------------------------------------ workgroup-staged tiles
+// One head's piece of a token row is 32 (hd 16) or 64 bytes (hd 32): a wavefront that fetches its own head reads 16
+// such pieces per load instruction, and HBM delivers 3.6 TB/s to that pattern against 5.1 TB/s for whole 128-byte lines
+// (profiles/r03_band_bf16_lab.txt).  So a workgroup = 4 neighbouring heads fetches the q / k / v tiles of its frames TOGETHER:
+// 16 token rows x (4 heads x hd) = rows of RB = 128 / 256 contiguous bytes, moved by LDS-DMA (16 bytes per lane, 1 KB per
+// instruction, no registers) one frame group ahead into a double buffer; each wave then reads its head's operands out of
+// LDS: row operands with ds_read_b64, column operands with ds_read_b64_tr_b16 straight from the same image.
+// The DMA writes LDS lane-linearly, so the bank swizzle is applied on the SOURCE side: LDS 16-byte slot c' of row r holds
+// the row's chunk c' ^ x(r), x = the row-pair index (hd 16) / row index (hd 32) rotated left by one bit: both kinds of
+// read are then conflict-free.
+template <int HD> struct Staged {
+    static constexpr int RB = 4 * HD * 2;                    // bytes per token row of a 4-head tile
+    static constexpr int TILE = 16 * RB;                     // 2 KB / 4 KB
+    static constexpr int NI = TILE / 1024;                   // DMA instructions per tile: 2 / 4
+    static constexpr int RPI = 16 / NI;                      // token rows per DMA instruction: 8 / 4
+    __device__ static __forceinline__ int xr(int row) {
+        if constexpr (HD == 16) { const int h = (row >> 1) & 7; return ((h & 3) << 1) | (h >> 2); }
+        else { const int h = row & 15; return ((h & 7) << 1) | (h >> 3); }
+    }
+    // byte offset inside a tile of the 8-byte piece p8 (0..3) of channels 16 ch .. 16 ch + 15 of head w in token row `row`
+    __device__ static __forceinline__ uint32_t piece(int row, int w, int ch, int p8) {
+        const int c = w * (HD / 8) + 2 * ch + (p8 >> 1);
+        return row * RB + ((c ^ xr(row)) << 4) + (p8 & 1) * 8;
+    }
+    // source byte offset (token rows of rs2 bytes) of this lane's 16 bytes in DMA instruction `ins` of a tile
+    __device__ static __forceinline__ uint32_t src(int lane, int ins, uint32_t rs2) {
+        const int row = ins * RPI + (lane * 16) / RB, cp = ((lane * 16) % RB) >> 4;
+        return row * rs2 + ((cp ^ xr(row)) << 4);
+    }
+};
+
+typedef __attribute__((address_space(3))) void* lds_void;
+__device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void wg_barrier() { asm volatile("s_barrier" ::: "memory"); }
+
+// unit = ((clip, window), segment, group of 4 heads): one workgroup; wave w of it owns head 4 hg + w
+struct Group16 {
+    int64_t tok0;
+    int hg, w, f0, f1;
+};
+__device__ __forceinline__ Group16 decode_group(const BandGeom& g, int blk) {
+    Group16 r;
+    const int n_hg = (g.nH + 3) >> 2;
+    r.hg = blk % n_hg;
+    int t = blk / n_hg;
+    const int sgi = t % g.n_seg;
+    t /= g.n_seg;
+    r.w = t % g.nW;
+    const int b = t / g.nW;
+    r.tok0 = (int64_t)b * g.F * g.K + r.w * 16;
+    r.f0 = sgi * g.seg;
+    r.f1 = min(g.F, r.f0 + g.seg);
+    return r;
+}
+
+template <int HD, int PF, int MINW, int DBG = 0>
+__global__ __launch_bounds__(256, MINW) void band_fwd_st_k(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
+                                                           const uint64_t* __restrict__ maskrows, BandGeom g,
+                                                           int64_t qkv_bytes) {
+    constexpr int NC = HD / 16;
+    using St = Staged<HD>;
+    constexpr int WPF = 4 / PF;                                  // waves sharing the DMA work of one frame
+    constexpr int IPW = St::NI / WPF;                            // DMA instructions per tile and wave
+    static_assert(PF == 4 || PF == 2, "frame group = 4 or 2 frames");
+    static_assert(St::NI % WPF == 0, "tile instructions split evenly over the waves of a frame");
+    constexpr int GROUP = PF * 3 * St::TILE;                     // one frame group: PF x (Q, K, V)
+    __shared__ __attribute__((aligned(1024))) char sm[2 * GROUP + 4 * NC * TTILE];   // [2][PF][3][TILE] | transposing tiles (prologue)
+    const int lane = threadIdx.x & 63, lr = lane & 15, gq = lane >> 4;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    char* vt = sm + 2 * GROUP + wib * (NC * TTILE);
+    const TileXpose xp(lane);
+    const Group16 un = decode_group(g, blockIdx.x);
+    const int head = 4 * un.hg + wib;
+    const bool live = head < g.nH;                               // waves past the last head stage tiles but compute nothing
+    const int hd_eff = min(head, g.nH - 1);
+    const int64_t rs = 3 * (int64_t)g.d;                         // qkv row stride (elements)
+    const bf16_t* gb = qkv + un.tok0 * rs + 4 * un.hg * HD;      // the group's q columns of (frame 0, joint 0)
+    const bf16_t* qb = qkv + un.tok0 * rs + hd_eff * HD;         // this wave's head (prologue loads)
+    bf16_t* ob = o + un.tok0 * (int64_t)g.d + hd_eff * HD;
+    const int64_t fs = (int64_t)g.K * rs;                        // frame stride in qkv
+    const uint32_t roff = lr * (uint32_t)rs + 4 * gq;            // per-lane offsets in qkv ...
+    const uint32_t ooff = lr * (uint32_t)g.d + 4 * gq;           // ... and in o
+    float bias[3][4];
+    band_bias(maskrows[un.w * 16 + lr], gq, bias);
+
+    // DMA: resource = from the group's first byte to the end of the tensor (lanes past it read zeros: a last head group
+    // of fewer than 4 heads stages columns that belong to no head)
+    const int64_t left = qkv_bytes - ((const char*)gb - (const char*)qkv);
+    const int span = (int)min(left, (int64_t)0x7fffffff);
+    uint32_t voff[IPW];
+#pragma unroll
+    for (int j = 0; j < IPW; ++j) voff[j] = St::src(lane, (wib % WPF) * IPW + j, (uint32_t)rs * 2);
+    const uint32_t fs2 = (uint32_t)fs * 2, d2 = (uint32_t)g.d * 2;
+    // wave w stages frame (w / WPF) of the group: Q of that frame, K and V of the frame after it
+    auto stage = [&](int buf, int fb) {
+        const int i = wib / WPF;
+        const int fq = min(fb + i, g.F - 1), fk = min(fb + i + 1, g.F - 1);    // clamped: such tiles are masked or unused
+        char* dst = sm + buf * GROUP + i * 3 * St::TILE + (wib % WPF) * IPW * 1024;
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)gb, 0, span, 0x00020000);
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int j = 0; j < IPW; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void)(dst + t * St::TILE + j * 1024), 16, (int)voff[j],   // (the cast matters: without it clang drops the host stub of this kernel)
+                                                         (t ? fk : fq) * fs2 + t * d2, 0, 0);
+    };
+    // this lane's read offsets inside a tile
+    uint32_t r_row[NC], r_col[NC];
+#pragma unroll
+    for (int ch = 0; ch < NC; ++ch) {
+        r_row[ch] = St::piece(lr, wib, ch, gq);
+        r_col[ch] = St::piece(4 * gq + (lr >> 2), wib, ch, lr & 3);
+    }
+    auto read_row = [&](const char* tile) {
+        Row16<NC> t;
+#pragma unroll
+        for (int ch = 0; ch < NC; ++ch) t.c[ch] = *(const lds_u32x2*)(tile + r_row[ch]);
+        return t;
+    };
+    auto read_col = [&](const char* tile) {
+        Col16<NC> t;
+#pragma unroll
+        for (int ch = 0; ch < NC; ++ch)
+            t.v[ch] = __builtin_bit_cast(pk4, __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + r_col[ch])));
+        return t;
+    };
+
+    stage(0, un.f0);
+    // sliding window: K (row operand) and V (column operand) of frames f-1, f, f+1; the first two straight from memory
+    Row16<NC> kw[3];
+    Col16<NC> vw[3];
+    kw[0] = zero_row16<NC>();
+    {
+        const int fp = max(un.f0 - 1, 0);                        // frame 0 stands in when there is none: masked by `edge`
+        const Row16<NC> vp = load_row16<NC>(qb + fp * fs + 2 * g.d, roff);
+        if (un.f0 > 0) kw[0] = load_row16<NC>(qb + fp * fs + g.d, roff);
+        vw[0] = to_col<NC>(xp, vt, vp);
+        kw[1] = load_row16<NC>(qb + un.f0 * fs + g.d, roff);
+        vw[1] = to_col<NC>(xp, vt, load_row16<NC>(qb + un.f0 * fs + 2 * g.d, roff));
+    }
+
+    int buf = 0;
+    for (int fb = un.f0; fb < un.f0 + g.seg; fb += PF, buf ^= 1) {
+        wait_vm0();                                              // this wave's share of the group has landed ...
+        wg_barrier();                                            // ... and everyone's; the other buffer is free again
+        stage(buf ^ 1, fb + PF);
+        const char* grp = sm + buf * GROUP;
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int f = fb + i;
+            const char* tq = grp + i * 3 * St::TILE;
+            const Row16<NC> q = read_row(tq);
+            kw[2] = read_row(tq + St::TILE);
+            vw[2] = read_col(tq + 2 * St::TILE);                 // outside the branch: the transposed read wants all lanes
+            if (DBG == 1) {
+                if (f < un.f1 && live) {
+                    bf16_t* of = ob + (int64_t)f * g.K * g.d;
+#pragma unroll
+                    for (int ct = 0; ct < NC; ++ct) *reinterpret_cast<pk4*>(of + ooff + 16 * ct) = q.c[ct] ^ kw[2].c[ct] ^ vw[2].v[ct];
+                }
+            } else if (f < un.f1 && live) {
                 f32x4v s[3], e[3];
 #pragma unroll
                 for (int t = 0; t < 3; ++t) s[t] = dot_rows16<NC>(kw[t], q);   // s[t][r] = S[q = lr][key = 4g + r]
@@ -262,7 +454,45 @@ __global__ __launch_bounds__(256, MINW) void band_fwd_b16_k(const bf16_t* __rest
             vw[0] = vw[1]; vw[1] = vw[2];
         }
     }
+    wait_vm0();                                                  // the last, unused prefetch group must land before the LDS is released
 }
+
+#ifdef HWGAT_LAB
+// memory pattern probe (lab): the forward kernel's bytes moved in whole 128-byte lines -- a workgroup (4 heads of hd 16)
+// reads the q, k, v tiles of its frames as 16-byte lanes, 8 lanes per token row, and writes o the same way; no arithmetic
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+template <int PF>
+__global__ __launch_bounds__(256, 4) void band_memtest_k(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, BandGeom g,
+                                                         int n_units) {
+    const int lane = threadIdx.x & 63, wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const Unit16 un = decode16(g, blockIdx.x * 4);               // head = first head of the group of 4
+    const int64_t rs = 3 * (int64_t)g.d;
+    const bf16_t* qb = qkv + un.tok0 * rs + un.head * 16;
+    bf16_t* ob = o + un.tok0 * (int64_t)g.d + un.head * 16;
+    const int64_t fs = (int64_t)g.K * rs;
+    const uint32_t roff = (lane >> 3) * (uint32_t)rs + 8 * (lane & 7), ooff = (lane >> 3) * (uint32_t)g.d + 8 * (lane & 7);
+    // per group of 4 frames: 4 x 3 tiles x 2 halves (8 rows) = 24 loads per workgroup, 6 per wave: wave w takes frame w
+    u32x4v ring[6];
+    auto fill = [&](int f) {
+        const int ff = min(f + wib, g.F - 1);
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+            ring[j] = *reinterpret_cast<const u32x4v*>(qb + ff * fs + (j >> 1) * g.d + (j & 1) * 8 * rs + roff);
+    };
+    fill(un.f0);
+    for (int fb = un.f0; fb < un.f0 + g.seg; fb += 4) {
+        __syncthreads();
+        u32x4v a = ring[0] ^ ring[2] ^ ring[4], b = ring[1] ^ ring[3] ^ ring[5];
+        fill(fb + 4);
+        const int f = fb + wib;
+        if (f < un.f1) {
+            bf16_t* of = ob + (int64_t)f * g.K * g.d;
+            *reinterpret_cast<u32x4v*>(of + ooff) = a;
+            *reinterpret_cast<u32x4v*>(of + 8 * g.d + ooff) = b;
+        }
+    }
+}
+#endif
 
 // =============================================================== backward
 // Unit = key frames [f0, f1) of one (clip, window, head): it walks the query frames f0-1 .. f1 (the two outer ones are
@@ -437,28 +667,50 @@ int segments(int64_t base_units, int F, int64_t want, int min_seg, const char* l
     return n_seg;
 }
 
+template <int HD, int PF, int MINW, int DBG = 0>
+int launch_fwd_st(const bf16_t* x, bf16_t* o, const uint64_t* maskrows, const BandGeom& g, int blocks, int64_t bytes, hipStream_t st) {
+    band_fwd_st_k<HD, PF, MINW, DBG><<<blocks, 256, 0, st>>>(x, o, maskrows, g, bytes);
+    HWGAT_LAUNCH_CHECK();
+}
+
 }  // namespace
 
 int hwgat_launch_band_fwd_b16(const void* qkv, void* o, const uint64_t* maskrows, int B, int F, int nW, int nH, int hd,
                               hipStream_t st) {
     const int64_t base_units = (int64_t)B * nW * nH;
-    int n_seg = segments(base_units, F, 256 * 4 * 4, 16, "HWGAT_BAND_FSEG");
+    int n_seg = segments(base_units, F, 256 * 4 * 2, 16, "HWGAT_BAND_FSEG");
     const int seg = (F + n_seg - 1) / n_seg;
     n_seg = (F + seg - 1) / seg;
     BandGeom g{F, nW * 16, nW, nH, nH * hd, seg, n_seg};
     const int64_t units = base_units * n_seg;
-    if (units > 0x7fffffff) return HWGAT_ESHAPE;
-    const int blocks = (int)((units + 3) / 4);
+    const int64_t clip_bytes = (int64_t)F * nW * 16 * 3 * nH * hd * 2;
+    if (units > 0x7fffffff || clip_bytes > 0x7fffffff) return HWGAT_ESHAPE;
+    const int64_t bytes = clip_bytes * B;
     const bf16_t* x = (const bf16_t*)qkv;
-    if (hd == 32) band_fwd_b16_k<32, 4, 2><<<blocks, 256, 0, st>>>(x, (bf16_t*)o, maskrows, g, (int)units);
-    else band_fwd_b16_k<16, 4, 4><<<blocks, 256, 0, st>>>(x, (bf16_t*)o, maskrows, g, (int)units);
-    HWGAT_LAUNCH_CHECK();
+    const int blocks_st = (int)((int64_t)B * nW * n_seg * ((nH + 3) / 4));
+#ifdef HWGAT_LAB
+    if (const char* e = lab_env("HWGAT_BAND_DBG")) {
+        const int blocks = (int)((units + 3) / 4);
+        const int dbg = atoi(e);
+        if (dbg == 1) band_fwd_b16_k<16, 4, 4, 1><<<blocks, 256, 0, st>>>(x, (bf16_t*)o, maskrows, g, (int)units);
+        else if (dbg == 2) band_fwd_b16_k<16, 4, 4, 2><<<blocks, 256, 0, st>>>(x, (bf16_t*)o, maskrows, g, (int)units);
+        else if (dbg == 3) band_fwd_b16_k<16, 4, 4, 3><<<blocks, 256, 0, st>>>(x, (bf16_t*)o, maskrows, g, (int)units);
+        else if (dbg == 4) band_memtest_k<4><<<blocks, 256, 0, st>>>(x, (bf16_t*)o, g, (int)units);
+        else if (dbg == 5) return launch_fwd_st<16, 4, 3, 1>(x, (bf16_t*)o, maskrows, g, blocks_st, bytes, st);
+        else if (dbg == 6) return launch_fwd_st<16, 2, 3>(x, (bf16_t*)o, maskrows, g, blocks_st, bytes, st);
+        else if (dbg == 7) band_fwd_b16_k<16, 4, 4><<<blocks, 256, 0, st>>>(x, (bf16_t*)o, maskrows, g, (int)units);
+        else return launch_fwd_st<16, 4, 3>(x, (bf16_t*)o, maskrows, g, blocks_st, bytes, st);
+        HWGAT_LAUNCH_CHECK();
+    }
+#endif
+    if (hd == 32) return launch_fwd_st<32, 2, 2>(x, (bf16_t*)o, maskrows, g, blocks_st, bytes, st);
+    return launch_fwd_st<16, 4, 3>(x, (bf16_t*)o, maskrows, g, blocks_st, bytes, st);
 }
 
 int hwgat_launch_band_bwd_b16(const void* qkv, const void* dO, void* dqkv, const uint64_t* maskrows, int B, int F, int nW,
                               int nH, int hd, hipStream_t st) {
     const int64_t base_units = (int64_t)B * nW * nH;
-    int n_seg = segments(base_units, F, 256 * 4 * 3, 16, "HWGAT_BAND_BSEG");
+    int n_seg = segments(base_units, F, 256 * 4 * 2, 16, "HWGAT_BAND_BSEG");
     const int seg = (F + n_seg - 1) / n_seg;
     n_seg = (F + seg - 1) / seg;
     BandGeom g{F, nW * 16, nW, nH, nH * hd, seg, n_seg};
