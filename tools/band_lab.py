@@ -49,3 +49,9 @@ for dbg, what in ((0, "shipped: workgroup-staged tiles"), (5, "staged, memory on
     us = t(lambda: HF.attn_fwd("band", qkv, o, rows, None, nH, False))
     print(f"fwd DBG={dbg} ({what}): {us:7.1f} us", flush=True)
 del os.environ["HWGAT_BAND_DBG"]
+
+for dbg, what in ((0, "shipped: staged, groups of 4 frames"), (6, "staged, groups of 2 frames"), (7, "one wave fetches its own head")):
+    os.environ["HWGAT_BAND_DBG"] = str(dbg)
+    us = t(lambda: HF.attn_bwd("band", qkv, do, dq, rows, None, nH, False))
+    print(f"bwd DBG={dbg} ({what}): {us:7.1f} us", flush=True)
+del os.environ["HWGAT_BAND_DBG"]
