@@ -187,7 +187,7 @@ __global__ __launch_bounds__(128, 2) void blk_attn_fwd_k(const T* __restrict__ q
 // (dK_w = sum_qt dS^T Q_qt, dV_w = sum_qt P^T dO_qt).  Q, K, dO live in LDS; V is only ever the
 // row-per-lane operand of dP, so it goes from HBM straight into registers.
 template <typename T, int HD>
-__global__ __launch_bounds__(128) void blk_attn_bwd_k(const T* __restrict__ qkv, const T* __restrict__ dO,
+__global__ __launch_bounds__(128, sizeof(T) == 2 ? 2 : 1) void blk_attn_bwd_k(const T* __restrict__ qkv, const T* __restrict__ dO,
                                                       T* __restrict__ dqkv,
                                                       const uint32_t* __restrict__ maskbits, BlkGeom g,
                                                       int n_units) {
