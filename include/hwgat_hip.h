@@ -123,6 +123,19 @@ int hwgat_win_attn_bwd(const void* qkv, const void* dO, void* dqkv, const uint32
                        const float* thr, int B, int F, int nW, int nH, int hd, int shifted,
                        int dtype, void* stream);
 
+/* the same pair with ATTENTION DROPOUT (reference HWGATE.py:78,112: nn.Dropout(attn_drop) on the softmax output,
+ * `attn_drop_rate` of HWGATE.py:273): the probabilities are multiplied by mask / (1 - drop_p) before the P V product.
+ * The mask is a hash of (drop_seed, element index of the reference's (B f nW, nH, 32, 32) attention tensor) and is
+ * recomputed by the backward: hwgat_dropout_mask_f32(out, B (F/2) nW nH 1024, drop_seed, drop_p) returns exactly it.
+ * drop_p in [0, 1); drop_p > 0 needs thr (dropout exists only in train mode), else HWGAT_EINVAL.
+ * hwgat_win_attn_fwd / _bwd are these with drop_p = 0. */
+int hwgat_win_attn_fwd_drop(const void* qkv, void* o, const uint32_t* maskbits, const float* thr,
+                            int B, int F, int nW, int nH, int hd, int shifted, int dtype,
+                            uint32_t drop_seed, float drop_p, void* stream);
+int hwgat_win_attn_bwd_drop(const void* qkv, const void* dO, void* dqkv, const uint32_t* maskbits,
+                            const float* thr, int B, int F, int nW, int nH, int hd, int shifted,
+                            int dtype, uint32_t drop_seed, float drop_p, void* stream);
+
 /* ---- (f) rank 3, sibling model HGATE: fused BLOCK attention (MSA.forward of
  * hwgat/models/HGATE.py:84-108) with block_partition / block_reverse / torch.roll
  * (HGATE.py:30-47,184-207) as index math.  A block is 2 frames x KJ joints (all joints

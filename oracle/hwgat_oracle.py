@@ -120,13 +120,16 @@ def from_windows(xw: torch.Tensor, tp: int = 2) -> torch.Tensor:
              .reshape(B, f * tp, nW * WINDOW, d)
 
 
-def window_attention(q, k, v, adj, smask=None, thr: Optional[float] = None):
+def window_attention(q, k, v, adj, smask=None, thr: Optional[float] = None, attn_keep=None):
     """Steps 1-8 of MSA.forward (HWGATE.py:89-114) for already-projected
     q,k,v of shape (B, f, nW, nH, 32, hd).
 
     adj: (nW, 32, 32) 0/1; smask: (f, nW, 32, 32) 0/1 or None;
-    thr: None for eval mode, else the train-mode probability threshold.
-    Returns o (B, f, nW, 32, nH*hd) and the final probabilities."""
+    thr: None for eval mode, else the train-mode probability threshold;
+    attn_keep: None, or the attention-dropout factor (B, f, nW, nH, 32, 32) = mask / (1 - p)
+    that nn.Dropout(attn_drop) applies to the probabilities (HWGATE.py:78,112) -- injected,
+    like the thresholds, so that parity does not depend on a random stream.
+    Returns o (B, f, nW, 32, nH*hd) and the final (undropped) probabilities."""
     hd = q.shape[-1]
     s = (q * hd ** -0.5) @ k.transpose(-2, -1)                 # :89-91
     if thr is not None:                                        # :94-100
@@ -138,7 +141,8 @@ def window_attention(q, k, v, adj, smask=None, thr: Optional[float] = None):
     s = s * adj[None, None, :, None]                           # :106-108
     s = s.masked_fill(s == 0, NEG_FILL)                        # :110
     p = torch.softmax(s, dim=-1)                               # :111
-    o = p @ v                                                  # :114
+    a = p if attn_keep is None else p * attn_keep              # :112
+    o = a @ v                                                  # :114
     B, f, nW, nH, n, _ = o.shape
     return o.permute(0, 1, 2, 4, 3, 5).reshape(B, f, nW, n, nH * hd), p
 

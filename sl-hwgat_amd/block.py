@@ -75,7 +75,7 @@ class _FusedBlock(torch.autograd.Function):
         # xc: the "carrier" the producing block handed over with x (or None).  It has no data (a 1-element tensor
         # expanded to x's shape); its only purpose is that THIS block's backward can return, as its gradient, the masked
         # copy of dx that the producing block needs in front of its fc2 dropout (cfg `up` = that dropout's seed).
-        bits, n_heads, shifted, p, seeds, kind, want_stats, merge_out, up, carry_out, book, deterministic = cfg
+        bits, n_heads, shifted, p, seeds, kind, want_stats, merge_out, up, carry_out, book, deterministic, attn_p = cfg
         ctx.set_materialize_grads(False)          # an unused carrier gradient arrives as None, not as a zero tensor
         B, F, K, d = x.shape
         dt = x.dtype                              # fp32, or bf16 activations with fp32 master weights
@@ -96,7 +96,7 @@ class _FusedBlock(torch.autograd.Function):
             m1, r1 = HF.ln_stats(x, n1w, n1b)
         qkv = HF.linear_nt_ln(x, wqkv, bqkv, (m1, r1, n1w, n1b))
         o = torch.empty_like(x)
-        HF.attn_fwd(kind, qkv, o, bits, thr, n_heads, shifted)
+        HF.attn_fwd(kind, qkv, o, bits, thr, n_heads, shifted, (seeds[3], attn_p) if attn_p > 0.0 else None)
         if fuse:
             y, m2, r2 = HF.linear_nt(o, cw(wp), bp, epi=HF.EPI_BIAS_DROP_RES, res=x, epi_seed=seeds[0], epi_p=p, stats=True)
         else:
@@ -129,7 +129,7 @@ class _FusedBlock(torch.autograd.Function):
     def backward(ctx, dout, _dmo, _dro, doutm=None):
         x, thr, n1w, n1b, wqkv, wp, n2w, n2b, w1, w2, m1, r1, qkv, o, y, m2, r2, h1, u = ctx.saved_tensors
         bits, n_heads, shifted, p, seeds, kind = ctx.cfg[:6]
-        up = ctx.cfg[8]
+        up, attn_p = ctx.cfg[8], ctx.cfg[12]
         B, F, K, d = x.shape
         dt = x.dtype
         book = ctx.book
@@ -191,7 +191,7 @@ class _FusedBlock(torch.autograd.Function):
             d_o = HF.linear_nt(d_y, HF.transpose(wp, dt), None, pro=HF.PRO_DROP, pro_seed=seeds[0], pro_p=p,
                                epi=HF.EPI_NONE, out=d_z)
         dqkv = torch.empty_like(qkv)
-        HF.attn_bwd(kind, qkv, d_o, dqkv, bits, thr, n_heads, shifted)
+        HF.attn_bwd(kind, qkv, d_o, dqkv, bits, thr, n_heads, shifted, (seeds[3], attn_p) if attn_p > 0.0 else None)
         if not xn_path:
             dwq.run(lambda: HF.linear_tn(dqkv, x, dwqkv, dbqkv, ln=(m1, r1, n1w, n1b)))
         d_xn = HF.linear_nt(dqkv, HF.transpose(wqkv, dt), None, epi=HF.EPI_NONE, out=d_o)
@@ -217,7 +217,7 @@ class _FusedBlock(torch.autograd.Function):
 
 def fused_block(x, thr, blk, bits, n_heads, shifted, p, seeds, kind="win", stats=None, want_stats=False,
                 merge_out=False, return_stats=False, carrier=None, up=None, carry_out=False, return_carrier=None,
-                book=None, deterministic=False):
+                book=None, deterministic=False, attn_p=0.0):
     """x (B,F,K,d) contiguous; `blk` holds norm1/attn.qkv/attn.proj/norm2/ff.fc1/ff.fc2.
     `kind`: 'win' = HWGATE part-window attention, 'blk' = HGATE block attention (thr must be None).
     `stats` = (mean, rstd) of the rows of x if the producer already has them; `want_stats`: have the fc2 epilogue produce
@@ -228,6 +228,7 @@ def fused_block(x, thr, blk, bits, n_heads, shifted, p, seeds, kind="win", stats
     loaders: `carry_out` makes this block return a data-less carrier next to `out`; the consumer passes it as `carrier`
     together with `up` = (this block's seeds[2], p) and returns the masked gradient as the carrier's gradient; both
     sides need the same `book` (functional.CarryBook of this forward call), without one no carrier is made or used.
+    `attn_p`: attention dropout rate (reference HWGATE.py:78,112; 'win' only, needs `thr` and a fourth seed, seeds[3]).
     `deterministic`: bit-reproducible forward (eval mode): statistics / merged store stay in the epilogue only where a
     row collects at most two atomic partials.
     Returns out, or (out, (mean, rstd) or None) with `return_stats`; with `carry_out` / `return_carrier` the carrier (or None) is appended."""
@@ -240,7 +241,7 @@ def fused_block(x, thr, blk, bits, n_heads, shifted, p, seeds, kind="win", stats
         blk.ff.fc1.weight, blk.ff.fc1.bias, blk.ff.fc2.weight, blk.ff.fc2.bias,
         (bits, n_heads, shifted, float(p), tuple(int(s) for s in seeds), kind, bool(want_stats), bool(merge_out),
          (int(up[0]), float(up[1])) if (up is not None and carrier is not None) else None, bool(carry_out),
-         book, bool(deterministic)))
+         book, bool(deterministic), float(attn_p)))
     oc = oc if oc.numel() else None
     if return_carrier is None:
         return_carrier = bool(carry_out)

@@ -26,6 +26,7 @@
 #include <stdlib.h>
 #include <type_traits>
 #include "attn_common.h"
+#include "fused_ops.h"            // the dropout hash (attention dropout)
 
 namespace {
 
@@ -101,12 +102,31 @@ __device__ __forceinline__ uint32_t masked_softmax(float (&s)[16], float (&p)[16
 }
 
 
+// Attention dropout (reference HWGATE.py:78,112: nn.Dropout on the softmax output, train mode).  keep[r] = 1/(1-p) or 0
+// for this lane's 16 probabilities P[q = lq][key = crow(r, hh)] of unit u.  The element index is the one of the
+// reference's (B_ = B f nW, nH, 32, 32) attention tensor, (u * 32 + q) * 32 + key, hashed like every other dropout
+// site (fused_ops.h): hwgat_dropout_mask_f32(out, units * 1024, seed, p) IS this mask (tests feed it to the oracle).
+struct AttnDrop {
+    uint32_t seed;
+    float p;                    // 0: no attention dropout
+};
+__device__ __forceinline__ void attn_keep(float (&k)[16], const AttnDrop& ad, int u, int lq, int hh) {
+    const uint64_t base = ((uint64_t)u * 32 + lq) * 32 + 4 * hh;
+    const uint32_t thresh = drop_thresh(ad.p);
+    const float scale = 1.0f / (1.0f - ad.p);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f32x4 t = drop_keep4(ad.seed, base + 8 * j, thresh, scale);
+        k[4 * j] = t.x; k[4 * j + 1] = t.y; k[4 * j + 2] = t.z; k[4 * j + 3] = t.w;
+    }
+}
+
 // =============================================================== forward
-template <typename T, int HD, bool TRAIN>
+template <typename T, int HD, bool TRAIN, bool ADROP = false>
 __global__ __launch_bounds__(256, 2) void win_attn_fwd_k(const T* __restrict__ qkv, T* __restrict__ o,
                                                          const uint32_t* __restrict__ maskbits,
                                                          const float* __restrict__ thr_p, WinGeom g,
-                                                         int n_units) {
+                                                         int n_units, AttnDrop ad) {
     using TL = tile_of<T>;             // fp32: fp32 tiles and MFMAs; bf16: raw bf16 tiles, v_mfma_f32_32x32x16_bf16 (attn_common.h)
     using E = typename TL::E;
     constexpr bool B16 = sizeof(T) == 2;
@@ -184,6 +204,12 @@ __global__ __launch_bounds__(256, 2) void win_attn_fwd_k(const T* __restrict__ q
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = TL::QSCALED ? st[r] : st[r] * qk_scale<HD>();
         masked_softmax<TRAIN>(s, p, mbits, hh, thr);
+        if constexpr (ADROP) {                                  // HWGATE.py:112
+            float keep[16];
+            attn_keep(keep, ad, u, lq, hh);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) p[r] *= keep[r];
+        }
 
         f32x16 oacc[NT];
 #pragma unroll
@@ -217,13 +243,13 @@ __global__ __launch_bounds__(256, 2) void win_attn_fwd_k(const T* __restrict__ q
 // =============================================================== backward
 
 // (bf16 tiles: 18 KiB of LDS per wave instead of 34, so two 4-wave workgroups share a CU)
-template <typename T, int HD, bool TRAIN, int WAVES>
+template <typename T, int HD, bool TRAIN, int WAVES, bool ADROP = false>
 __global__ __launch_bounds__(WAVES * 64, (sizeof(T) == 2 && HD <= 64) ? 2 : 1) void win_attn_bwd_k(const T* __restrict__ qkv,
                                                                 const T* __restrict__ dO,
                                                                 T* __restrict__ dqkv,
                                                                 const uint32_t* __restrict__ maskbits,
                                                                 const float* __restrict__ thr_p,
-                                                                WinGeom g, int n_units) {
+                                                                WinGeom g, int n_units, AttnDrop ad) {
     using TL = tile_of<T>;                                   // see win_attn_fwd_k
     using E = typename TL::E;
     constexpr int LDW = HD + TL::PAD;
@@ -295,13 +321,23 @@ __global__ __launch_bounds__(WAVES * 64, (sizeof(T) == 2 && HD <= 64) ? 2 : 1) v
         const uint32_t nz = masked_softmax<TRAIN>(s, p, mbits, hh, thr);
         // dP^T[key][q] = V dO^T
         {
-            f32x16 dp = tile_xyT<HD, LDW>(Vs, Gs, lq, hh);
+            f32x16 dp = tile_xyT<HD, LDW>(Vs, Gs, lq, hh);  // with attention dropout this is dA, A = D o P: dP = D o dA
+            float keep[ADROP ? 16 : 1];
+            if constexpr (ADROP) {
+                attn_keep(keep, ad, u, lq, hh);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dp[r] *= keep[r];
+            }
             float delta = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) delta += p[r] * dp[r];
             delta += partner(delta);
 #pragma unroll
             for (int r = 0; r < 16; ++r) ds[r] = ((nz >> r) & 1u) ? p[r] * (dp[r] - delta) : 0.f;
+            if constexpr (ADROP) {                            // dV = A^T dO
+#pragma unroll
+                for (int r = 0; r < 16; ++r) p[r] *= keep[r];
+            }
         }
         lds_fence();                                          // V tile is dead from here on
         // transpose P and dS through LDS: write [q][key], later read [.][key = lane]
@@ -348,12 +384,12 @@ __global__ __launch_bounds__(WAVES * 64, (sizeof(T) == 2 && HD <= 64) ? 2 : 1) v
 // products that contract over head_dim, S = (scale Q) K^T and dP = dO V^T, are formed as per-half partial sums and
 // exchanged through an 8 KiB LDS mailbox (a + b on one side, b + a on the other: bit-identical, so both waves
 // run the same softmax); dQ, dK, dV split by columns and need no reduction.  160 MFMAs per wave and unit.
-template <typename T, bool TRAIN>
+template <typename T, bool TRAIN, bool ADROP = false>
 __global__ __launch_bounds__(128, sizeof(T) == 2 ? 3 : 2) void win_attn_bwd_split_k(const T* __restrict__ qkv, const T* __restrict__ dO,
                                                                T* __restrict__ dqkv,
                                                                const uint32_t* __restrict__ maskbits,
                                                                const float* __restrict__ thr_p, WinGeom g,
-                                                               int n_units) {
+                                                               int n_units, AttnDrop ad) {
     using TL = tile_of<T>;                                     // see win_attn_fwd_k
     using E = typename TL::E;
     constexpr int HD = 128, HW = 64, LDW = HW + TL::PAD, NT = HW / 32;
@@ -449,12 +485,22 @@ __global__ __launch_bounds__(128, sizeof(T) == 2 ? 3 : 2) void win_attn_bwd_spli
             post(dt);
             __syncthreads();
             collect(dt, dp);
+            float keep[ADROP ? 16 : 1];
+            if constexpr (ADROP) {                            // dP = D o dA (see win_attn_bwd_k)
+                attn_keep(keep, ad, u, lq, hh);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dp[r] *= keep[r];
+            }
             float delta = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) delta += p[r] * dp[r];
             delta += partner(delta);
 #pragma unroll
             for (int r = 0; r < 16; ++r) ds[r] = ((nz >> r) & 1u) ? p[r] * (dp[r] - delta) : 0.f;
+            if constexpr (ADROP) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) p[r] *= keep[r];
+            }
         }
         lds_fence();                                          // this wave's V tile is dead from here on
 #pragma unroll
@@ -576,37 +622,43 @@ bool geom_ok(int B, int F, int nW, int nH, int hd) {
 }
 
 template <typename T, int HD>
-int launch_fwd(const void* qkv, void* o, const uint32_t* mb, const float* thr, WinGeom g, int n_units,
+int launch_fwd(const void* qkv, void* o, const uint32_t* mb, const float* thr, WinGeom g, int n_units, AttnDrop ad,
                hipStream_t st) {
     const int blocks = min((n_units + 3) / 4, 256 * 2);         // (three resident workgroups with bf16 tiles: 130 vs 123 us, no gain)
-    if (thr)
-        win_attn_fwd_k<T, HD, true><<<blocks, 256, 0, st>>>((const T*)qkv, (T*)o, mb, thr, g, n_units);
+    if (thr && ad.p > 0.f)
+        win_attn_fwd_k<T, HD, true, true><<<blocks, 256, 0, st>>>((const T*)qkv, (T*)o, mb, thr, g, n_units, ad);
+    else if (thr)
+        win_attn_fwd_k<T, HD, true><<<blocks, 256, 0, st>>>((const T*)qkv, (T*)o, mb, thr, g, n_units, ad);
     else
-        win_attn_fwd_k<T, HD, false><<<blocks, 256, 0, st>>>((const T*)qkv, (T*)o, mb, thr, g, n_units);
+        win_attn_fwd_k<T, HD, false><<<blocks, 256, 0, st>>>((const T*)qkv, (T*)o, mb, thr, g, n_units, ad);
     HWGAT_LAUNCH_CHECK();
 }
 template <typename T, int HD>
 int launch_bwd(const void* qkv, const void* dO, void* dqkv, const uint32_t* mb, const float* thr,
-               WinGeom g, int n_units, hipStream_t st) {
+               WinGeom g, int n_units, AttnDrop ad, hipStream_t st) {
+#define BWD_ARGS (const T*)qkv, (const T*)dO, (T*)dqkv, mb, thr, g, n_units, ad
     if constexpr (HD == 128) {                               // two waves per unit, four waves per CU (see win_attn_bwd_split_k)
         static const bool whole = [] { const char* e = lab_env("HWGAT_ATTN_SPLIT"); return e && e[0] == '0'; }();
         if (!whole) {
             const int blocks = min(n_units, 256 * (sizeof(T) == 2 ? 3 : 2));   // bf16 tiles: 44 KiB per workgroup
-            if (thr)
-                win_attn_bwd_split_k<T, true><<<blocks, 128, 0, st>>>((const T*)qkv, (const T*)dO, (T*)dqkv, mb, thr, g, n_units);
-            else
-                win_attn_bwd_split_k<T, false><<<blocks, 128, 0, st>>>((const T*)qkv, (const T*)dO, (T*)dqkv, mb, thr, g, n_units);
+            if (thr && ad.p > 0.f) win_attn_bwd_split_k<T, true, true><<<blocks, 128, 0, st>>>(BWD_ARGS);
+            else if (thr) win_attn_bwd_split_k<T, true><<<blocks, 128, 0, st>>>(BWD_ARGS);
+            else win_attn_bwd_split_k<T, false><<<blocks, 128, 0, st>>>(BWD_ARGS);
             HWGAT_LAUNCH_CHECK();
         }
     }
     constexpr int WAVES = HD <= 64 ? 4 : 2;                  // 4 x 34 KiB or 2 x 66 KiB of LDS per CU
     const int blocks = min((n_units + WAVES - 1) / WAVES, (sizeof(T) == 2 && HD <= 64) ? 512 : 256);
-    if (thr)
-        win_attn_bwd_k<T, HD, true, WAVES><<<blocks, WAVES * 64, 0, st>>>((const T*)qkv, (const T*)dO, (T*)dqkv, mb, thr, g, n_units);
-    else
-        win_attn_bwd_k<T, HD, false, WAVES><<<blocks, WAVES * 64, 0, st>>>((const T*)qkv, (const T*)dO, (T*)dqkv, mb, thr, g, n_units);
+    if (thr && ad.p > 0.f) win_attn_bwd_k<T, HD, true, WAVES, true><<<blocks, WAVES * 64, 0, st>>>(BWD_ARGS);
+    else if (thr) win_attn_bwd_k<T, HD, true, WAVES><<<blocks, WAVES * 64, 0, st>>>(BWD_ARGS);
+    else win_attn_bwd_k<T, HD, false, WAVES><<<blocks, WAVES * 64, 0, st>>>(BWD_ARGS);
+#undef BWD_ARGS
     HWGAT_LAUNCH_CHECK();
 }
+
+// attention dropout only exists in train mode (thr given); p in [0, 1)
+bool drop_ok(const float* thr, float p) { return p >= 0.f && p < 1.f && (p == 0.f || thr); }
+AttnDrop make_drop(uint32_t seed, float p) { return AttnDrop{seed, p < 0.5f / 65536.0f ? 0.f : p}; }   // p is quantised to 1/65536 (fused_ops.h)
 
 }  // namespace
 
@@ -628,20 +680,21 @@ extern "C" int hwgat_debug_mfma_peak(float* out, int blocks, int iters, int n_ac
     HWGAT_LAUNCH_CHECK();
 }
 
-extern "C" int hwgat_win_attn_fwd(const void* qkv, void* o, const uint32_t* maskbits, const float* thr,
-                                  int B, int F, int nW, int nH, int hd, int shifted, int dtype,
-                                  void* stream) {
-    if (!qkv || !o || !maskbits) return HWGAT_EINVAL;
+extern "C" int hwgat_win_attn_fwd_drop(const void* qkv, void* o, const uint32_t* maskbits, const float* thr,
+                                       int B, int F, int nW, int nH, int hd, int shifted, int dtype,
+                                       uint32_t drop_seed, float drop_p, void* stream) {
+    if (!qkv || !o || !maskbits || !drop_ok(thr, drop_p)) return HWGAT_EINVAL;
     if (!geom_ok(B, F, nW, nH, hd)) return HWGAT_ESHAPE;
     WinGeom g{F, nW * 16, nW, nH, F / 2, nH * hd, shifted ? 1 : 0};
     const int64_t units = (int64_t)B * g.f * nW * nH;
     if (units > 0x7fffffff) return HWGAT_ESHAPE;
     hipStream_t st = (hipStream_t)stream;
-#define FWD(T)                                                                                  \
-    switch (hd) {                                                                               \
-        case 32: return launch_fwd<T, 32>(qkv, o, maskbits, thr, g, (int)units, st);            \
-        case 64: return launch_fwd<T, 64>(qkv, o, maskbits, thr, g, (int)units, st);            \
-        default: return launch_fwd<T, 128>(qkv, o, maskbits, thr, g, (int)units, st);           \
+    const AttnDrop ad = make_drop(drop_seed, drop_p);
+#define FWD(T)                                                                                      \
+    switch (hd) {                                                                                   \
+        case 32: return launch_fwd<T, 32>(qkv, o, maskbits, thr, g, (int)units, ad, st);            \
+        case 64: return launch_fwd<T, 64>(qkv, o, maskbits, thr, g, (int)units, ad, st);            \
+        default: return launch_fwd<T, 128>(qkv, o, maskbits, thr, g, (int)units, ad, st);           \
     }
     if (dtype == HWGAT_F32) { FWD(float) }
     if (dtype == HWGAT_BF16) { FWD(bf16_t) }
@@ -649,23 +702,36 @@ extern "C" int hwgat_win_attn_fwd(const void* qkv, void* o, const uint32_t* mask
     return HWGAT_EDTYPE;
 }
 
-extern "C" int hwgat_win_attn_bwd(const void* qkv, const void* dO, void* dqkv, const uint32_t* maskbits,
-                                  const float* thr, int B, int F, int nW, int nH, int hd, int shifted,
-                                  int dtype, void* stream) {
-    if (!qkv || !dO || !dqkv || !maskbits) return HWGAT_EINVAL;
+extern "C" int hwgat_win_attn_fwd(const void* qkv, void* o, const uint32_t* maskbits, const float* thr,
+                                  int B, int F, int nW, int nH, int hd, int shifted, int dtype,
+                                  void* stream) {
+    return hwgat_win_attn_fwd_drop(qkv, o, maskbits, thr, B, F, nW, nH, hd, shifted, dtype, 0u, 0.f, stream);
+}
+
+extern "C" int hwgat_win_attn_bwd_drop(const void* qkv, const void* dO, void* dqkv, const uint32_t* maskbits,
+                                       const float* thr, int B, int F, int nW, int nH, int hd, int shifted,
+                                       int dtype, uint32_t drop_seed, float drop_p, void* stream) {
+    if (!qkv || !dO || !dqkv || !maskbits || !drop_ok(thr, drop_p)) return HWGAT_EINVAL;
     if (!geom_ok(B, F, nW, nH, hd)) return HWGAT_ESHAPE;
     WinGeom g{F, nW * 16, nW, nH, F / 2, nH * hd, shifted ? 1 : 0};
     const int64_t units = (int64_t)B * g.f * nW * nH;
     if (units > 0x7fffffff) return HWGAT_ESHAPE;
     hipStream_t st = (hipStream_t)stream;
-#define BWD(T)                                                                                        \
-    switch (hd) {                                                                                     \
-        case 32: return launch_bwd<T, 32>(qkv, dO, dqkv, maskbits, thr, g, (int)units, st);           \
-        case 64: return launch_bwd<T, 64>(qkv, dO, dqkv, maskbits, thr, g, (int)units, st);           \
-        default: return launch_bwd<T, 128>(qkv, dO, dqkv, maskbits, thr, g, (int)units, st);          \
+    const AttnDrop ad = make_drop(drop_seed, drop_p);
+#define BWD(T)                                                                                            \
+    switch (hd) {                                                                                         \
+        case 32: return launch_bwd<T, 32>(qkv, dO, dqkv, maskbits, thr, g, (int)units, ad, st);           \
+        case 64: return launch_bwd<T, 64>(qkv, dO, dqkv, maskbits, thr, g, (int)units, ad, st);           \
+        default: return launch_bwd<T, 128>(qkv, dO, dqkv, maskbits, thr, g, (int)units, ad, st);          \
     }
     if (dtype == HWGAT_F32) { BWD(float) }
     if (dtype == HWGAT_BF16) { BWD(bf16_t) }
 #undef BWD
     return HWGAT_EDTYPE;
+}
+
+extern "C" int hwgat_win_attn_bwd(const void* qkv, const void* dO, void* dqkv, const uint32_t* maskbits,
+                                  const float* thr, int B, int F, int nW, int nH, int hd, int shifted,
+                                  int dtype, void* stream) {
+    return hwgat_win_attn_bwd_drop(qkv, dO, dqkv, maskbits, thr, B, F, nW, nH, hd, shifted, dtype, 0u, 0.f, stream);
 }

@@ -158,33 +158,45 @@ def layer_norm(x, gamma, beta):
 # ---------------------------------------------------------------- attention
 class _WinAttn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, qkv, bits, thr, n_heads, shifted):
+    def forward(ctx, qkv, bits, thr, n_heads, shifted, drop):
         B, F, K, d3 = qkv.shape
         d = d3 // 3
         o = torch.empty(B, F, K, d, device=qkv.device, dtype=qkv.dtype)
-        call("hwgat_win_attn_fwd", ptr(qkv), ptr(o), ptr(bits), ptr(thr), B, F, K // 16, n_heads,
-             d // n_heads, int(shifted), dtype_code(qkv), stream())
+        attn_fwd("win", qkv, o, bits, thr, n_heads, shifted, drop)
         ctx.save_for_backward(qkv, bits, thr)
-        ctx.cfg = (n_heads, int(shifted))
+        ctx.cfg = (n_heads, int(shifted), drop)
         return o
 
     @staticmethod
     def backward(ctx, do):
         qkv, bits, thr = ctx.saved_tensors
-        n_heads, shifted = ctx.cfg
-        B, F, K, d3 = qkv.shape
-        d = d3 // 3
+        n_heads, shifted, drop = ctx.cfg
         do = do.contiguous()
         dqkv = torch.empty_like(qkv)
-        call("hwgat_win_attn_bwd", ptr(qkv), ptr(do), ptr(dqkv), ptr(bits), ptr(thr), B, F, K // 16,
-             n_heads, d // n_heads, shifted, dtype_code(qkv), stream())
-        return dqkv, None, None, None, None
+        attn_bwd("win", qkv, do, dqkv, bits, thr, n_heads, shifted, drop)
+        return dqkv, None, None, None, None, None
 
 
-def attn_fwd(kind, qkv, o, bits, thr, n_heads, shifted):
-    """launch the attention forward of a model family: 'win' = HWGATE part windows, 'blk' = HGATE blocks"""
+def _attn_drop(kind, thr, drop):
+    """(seed, p) of the attention dropout (reference HWGATE.py:78,112) or None; only the HWGATE window kernels have it"""
+    if drop is None or float(drop[1]) <= 0.0:
+        return None
+    if kind != "win":
+        raise NotImplementedError("attention dropout exists for the HWGATE window attention only")
+    if thr is None:
+        raise ValueError("attention dropout is a train-mode operation: it needs the train-mode threshold tensor")
+    return int(drop[0]) & 0xFFFFFFFF, float(drop[1])
+
+
+def attn_fwd(kind, qkv, o, bits, thr, n_heads, shifted, drop=None):
+    """launch the attention forward of a model family: 'win' = HWGATE part windows, 'blk' = HGATE blocks, 'band' = WGATE.
+    `drop` = (seed, p): attention dropout ('win', train mode only)"""
     B, F, K, d = o.shape
-    if kind == "win":
+    drop = _attn_drop(kind, thr, drop)
+    if kind == "win" and drop is not None:
+        call("hwgat_win_attn_fwd_drop", ptr(qkv), ptr(o), ptr(bits), ptr(thr), B, F, K // 16, n_heads, d // n_heads,
+             int(shifted), dtype_code(qkv), drop[0], drop[1], stream())
+    elif kind == "win":
         call("hwgat_win_attn_fwd", ptr(qkv), ptr(o), ptr(bits), ptr(thr), B, F, K // 16, n_heads, d // n_heads,
              int(shifted), dtype_code(qkv), stream())
     elif kind == "blk":
@@ -199,9 +211,13 @@ def attn_fwd(kind, qkv, o, bits, thr, n_heads, shifted):
         raise ValueError(kind)
 
 
-def attn_bwd(kind, qkv, do, dqkv, bits, thr, n_heads, shifted):
+def attn_bwd(kind, qkv, do, dqkv, bits, thr, n_heads, shifted, drop=None):
     B, F, K, d = do.shape
-    if kind == "win":
+    drop = _attn_drop(kind, thr, drop)
+    if kind == "win" and drop is not None:
+        call("hwgat_win_attn_bwd_drop", ptr(qkv), ptr(do), ptr(dqkv), ptr(bits), ptr(thr), B, F, K // 16, n_heads,
+             d // n_heads, int(shifted), dtype_code(qkv), drop[0], drop[1], stream())
+    elif kind == "win":
         call("hwgat_win_attn_bwd", ptr(qkv), ptr(do), ptr(dqkv), ptr(bits), ptr(thr), B, F, K // 16, n_heads,
              d // n_heads, int(shifted), dtype_code(qkv), stream())
     elif kind == "blk":
@@ -263,10 +279,12 @@ def block_attention(qkv, bits, n_heads, shifted):
     return _BlkAttn.apply(qkv.contiguous(), bits, n_heads, shifted)
 
 
-def window_attention(qkv, bits, thr, n_heads, shifted):
+def window_attention(qkv, bits, thr, n_heads, shifted, drop=None):
     """qkv (B,F,K,3d) -> o (B,F,K,d).  `thr`: 1-element fp32 device tensor
-    (train mode) or None (eval mode)."""
-    return _WinAttn.apply(qkv.contiguous(), bits, thr, n_heads, shifted)
+    (train mode) or None (eval mode).  `drop` = (seed, p): attention dropout on the
+    probabilities (reference HWGATE.py:112), train mode only."""
+    drop = _attn_drop("win", thr, drop)
+    return _WinAttn.apply(qkv.contiguous(), bits, thr, n_heads, shifted, drop)
 
 
 # ---------------------------------------------------------------- merge

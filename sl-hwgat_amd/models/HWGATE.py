@@ -64,8 +64,8 @@ class Model(nn.Module):
             raise NotImplementedError("HWGAT HIP backend supports temporal_patch_size == 2")
         if window_size != 16:
             raise NotImplementedError("HWGAT HIP backend supports window_size == 16")
-        if attn_drop_rate != 0.0:
-            raise NotImplementedError("attn_drop_rate must be 0 (the reference default)")
+        if not 0.0 <= float(attn_drop_rate) < 1.0:
+            raise ValueError("attn_drop_rate must be in [0, 1)")
         if norm_layer is not nn.LayerNorm:
             raise NotImplementedError("norm_layer must be nn.LayerNorm")
         assert num_kps % window_size == 0, "window size and number of kps are incompatible"
@@ -76,6 +76,7 @@ class Model(nn.Module):
         self.num_classes, self.embed_dim, self.pe = num_classes, embed_dim, pe
         self.depths, self.num_heads = list(depths), list(num_heads)
         self.drop_rate, self.ff_ratio = float(drop_rate), ff_ratio
+        self.attn_drop_rate = float(attn_drop_rate)          # nn.Dropout on the attention probabilities (HWGATE.py:78,112)
         self.num_layers = n_stage
         self.num_features = int(embed_dim * 2 ** (n_stage - 1))
         self.n_windows = num_kps // 16
@@ -142,13 +143,16 @@ class Model(nn.Module):
         return self
 
     # ------------------------------------------------------------ forward
+    attn_drop_rate = 0.0      # the sibling models (HGATE / WGATE constructors) have no attention dropout
+
     def _seeds(self, k):
-        """three dropout-site seeds for block k of this forward call (host integers, no sync)"""
+        """four dropout-site seeds for block k of this forward call (host integers, no sync): proj, fc1, fc2 outputs
+        (HWGATE.py:116,133,135) and the attention probabilities (HWGATE.py:112)"""
         # rank_salt: data-parallel ranks share torch's seed (identical initial weights) but must not share
         # dropout masks (SURVEY 8e); dist.broadcast_parameters() sets it to the rank
         base = (torch.initial_seed() * 0x9E3779B1 + self._drop_calls * 0x85EBCA77
                 + getattr(self, "rank_salt", 0) * 0x27D4EB2F) & 0xFFFFFFFF
-        return [(base + (k * 4 + s) * 0xC2B2AE35) & 0xFFFFFFFF for s in range(3)]
+        return [(base + (k * 4 + s) * 0xC2B2AE35) & 0xFFFFFFFF for s in range(4)]
 
     def _block(self, h, blk, n_heads, shifted, thr, k, hand):
         """one PartAttentionBlock (HWGATE.py:189-221) = one fused autograd node (block.fused_block).  `hand` is the
@@ -166,7 +170,8 @@ class Model(nn.Module):
         out, st, oc = fused_block(h, thr, blk, self._mask_bits, n_heads, shifted, p, seeds, self._attn_kind,
                                   stats=have, want_stats=want, merge_out=merge, return_stats=True,
                                   carrier=carrier, up=up, carry_out=(want or k == hand.last_block) and not merge,
-                                  return_carrier=True, book=hand.book, deterministic=hand.deterministic)
+                                  return_carrier=True, book=hand.book, deterministic=hand.deterministic,
+                                  attn_p=self.attn_drop_rate if self.training else 0.0)
         hand.of, hand.stats, hand.carrier, hand.up = out, st, oc, ((seeds[2], p) if oc is not None else None)
         return out
 

@@ -485,7 +485,7 @@ def test_gelu_factor_stored_forward_multiplied_backward(M, N, K, dtype):
 
 
 def test_dropout_masks_of_different_sites_seeds_and_ranks_are_independent():
-    """the counter-based mask hash (fused_ops.h mix32): masks drawn for neighbouring seeds, for the three dropout sites
+    """the counter-based mask hash (fused_ops.h mix32): masks drawn for neighbouring seeds, for the four dropout sites
     of a block, for two data-parallel ranks (rank_salt) and for two consecutive calls must be uncorrelated, and a mask
     must not be correlated with itself at small lags (two elements share one 32-bit hash).  1e6 elements: the sample
     correlation of independent masks has a standard deviation of 1e-3, the bound is 1e-2."""
@@ -510,7 +510,8 @@ def test_dropout_masks_of_different_sites_seeds_and_ranks_are_independent():
         return float((a * b).mean() / (a.std() * b.std()))
 
     base = mask(s_rank0[0])
-    pairs = {"site 0 vs 1": mask(s_rank0[1]), "site 0 vs 2": mask(s_rank0[2]), "rank 0 vs 1": mask(s_rank1[0]),
+    pairs = {"site 0 vs 1": mask(s_rank0[1]), "site 0 vs 2": mask(s_rank0[2]), "site 0 vs 3 (attention)": mask(s_rank0[3]),
+             "rank 0 vs 1": mask(s_rank1[0]),
              "call n vs n+1": mask(s_next[0]), "seed vs seed+1": mask((s_rank0[0] + 1) & 0xFFFFFFFF),
              "seed vs seed^bit31": mask(s_rank0[0] ^ 0x80000000)}
     worst = 0.0

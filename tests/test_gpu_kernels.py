@@ -17,7 +17,7 @@ DEV = "cuda:0"
 F32_TOL, BF16_TOL = 2e-5, 1e-2
 
 
-def _oracle_attn(qkv, adj, n_heads, shifted, thr):
+def _oracle_attn(qkv, adj, n_heads, shifted, thr, attn_keep=None):
     """natural-order qkv (B,F,K,3d) fp64 -> o (B,F,K,d) with the oracle's
     roll / partition / attention / reverse / roll chain"""
     B, F, K, d3 = qkv.shape
@@ -27,7 +27,7 @@ def _oracle_attn(qkv, adj, n_heads, shifted, thr):
     w = O.to_windows(x)                                             # (B,f,nW,32,3d)
     w = w.reshape(B, F // 2, nW, 32, 3, n_heads, hd).permute(4, 0, 1, 2, 5, 3, 6)
     sm = O.shift_mask(F, nW, 2, 1, qkv.dtype).view(F // 2, nW, 32, 32) if shifted else None
-    o, _ = O.window_attention(w[0], w[1], w[2], adj.to(qkv.dtype), sm, thr)
+    o, _ = O.window_attention(w[0], w[1], w[2], adj.to(qkv.dtype), sm, thr, attn_keep)
     o = O.from_windows(o)
     return torch.roll(o, 1, 1) if shifted else o
 
@@ -79,6 +79,56 @@ def test_window_attention_fwd_bwd(hd, nH, nW, F, B, shifted, thr):
     if thr is None or thr > 0.9:          # threshold selectors can flip under bf16 rounding of S
         assert rel_err(outb.detach().float().cpu(), refb.detach()) < BF16_TOL
         assert rel_err(xb.grad.float().cpu(), refb_in.grad) < 2 * BF16_TOL
+
+
+@pytest.mark.parametrize("hd,nH,nW,F,B", [(64, 2, 2, 8, 2), (128, 2, 1, 6, 2), (32, 4, 3, 4, 1)])
+@pytest.mark.parametrize("shifted", [False, True])
+def test_window_attention_with_attention_dropout(hd, nH, nW, F, B, shifted):
+    """attn_drop_rate > 0 (reference HWGATE.py:78,112): the kernels' mask is the library's own hash over the element
+    index of the reference's (B f nW, nH, 32, 32) attention tensor, so hwgat_dropout_mask_f32 hands it to the oracle;
+    forward and backward (which recomputes the mask), fp32 and bf16 storage, all three backward kernels (hd 128 = the
+    two-wave split form).  The threshold is set where no selector is close to a tie."""
+    g = torch.Generator().manual_seed(3 * hd + nW + F)
+    d, K, p_drop, seed, thr = nH * hd, nW * 16, 0.2, 0xC0FFEE, 0.9999
+    qkv = torch.randn(B, F, K, 3 * d, generator=g) * 0.8
+    do = torch.randn(B, F, K, d, generator=g)
+    adj = O.window_adjacency(nW)
+    bits = HF.mask_bits(adj).to(DEV)
+    thr_t = torch.tensor([thr], device=DEV)
+    keep = HF.dropout_mask((B, F // 2, nW, nH, 32, 32), seed, p_drop, DEV).cpu().double()
+    kept = keep[keep > 0]
+    assert float((kept - 1.0 / (1.0 - p_drop)).abs().max()) < 1e-6 and abs(kept.numel() / keep.numel() - (1 - p_drop)) < 0.02
+
+    ref_in = qkv.double().requires_grad_(True)
+    ref = _oracle_attn(ref_in, adj, nH, shifted, thr, keep)
+    ref.backward(do.double())
+    x = qkv.to(DEV).requires_grad_(True)
+    out = HF.window_attention(x, bits, thr_t, nH, shifted, drop=(seed, p_drop))
+    out.backward(do.to(DEV))
+    assert rel_err(out.detach().cpu(), ref.detach()) < F32_TOL
+    assert rel_err(x.grad.cpu(), ref_in.grad) < F32_TOL
+    # a different seed is a different mask; p = 0 is the plain kernel, bit for bit
+    other = HF.window_attention(x.detach(), bits, thr_t, nH, shifted, drop=(seed + 1, p_drop))
+    assert rel_err(other.cpu(), ref.detach()) > 0.05
+    assert torch.equal(HF.window_attention(x.detach(), bits, thr_t, nH, shifted, drop=(seed, 0.0)),
+                       HF.window_attention(x.detach(), bits, thr_t, nH, shifted))
+
+    xb = qkv.to(DEV, torch.bfloat16).requires_grad_(True)
+    refb_in = xb.detach().cpu().double().requires_grad_(True)
+    refb = _oracle_attn(refb_in, adj, nH, shifted, thr, keep)
+    refb.backward(do.double())
+    outb = HF.window_attention(xb, bits, thr_t, nH, shifted, drop=(seed, p_drop))
+    outb.backward(do.to(DEV, torch.bfloat16))
+    assert rel_err(outb.detach().float().cpu(), refb.detach()) < BF16_TOL
+    assert rel_err(xb.grad.float().cpu(), refb_in.grad) < 2 * BF16_TOL
+
+    # eval mode has no dropout: asking for it without the train-mode threshold is an error, in Python and in the C-ABI
+    with pytest.raises(ValueError):
+        HF.window_attention(x.detach(), bits, None, nH, shifted, drop=(seed, p_drop))
+    L = hw._lib
+    o = torch.empty(B, F, K, d, device=DEV)
+    assert L.lib().hwgat_win_attn_fwd_drop(L.ptr(x), L.ptr(o), L.ptr(bits), None, B, F, nW, nH, hd, int(shifted), 0, seed, p_drop, None) < 0
+    assert L.lib().hwgat_win_attn_fwd_drop(L.ptr(x), L.ptr(o), L.ptr(bits), L.ptr(thr_t), B, F, nW, nH, hd, int(shifted), 0, seed, 1.0, None) < 0
 
 
 def test_window_attention_edge_rows():

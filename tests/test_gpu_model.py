@@ -182,9 +182,11 @@ def test_dropout_train_mode_runs_and_is_stochastic():
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
 
 
-def test_fused_dropout_matches_unfused_math_with_same_masks():
-    """train mode, drop 0.1: the fused block must equal a plain-torch evaluation that uses the
-    very masks the kernels generate (hwgat_dropout_mask_f32) -- forward and input gradient."""
+@pytest.mark.parametrize("attn_p", [0.0, 0.15])
+def test_fused_dropout_matches_unfused_math_with_same_masks(attn_p):
+    """train mode, drop 0.1 (and attention dropout 0.15, reference HWGATE.py:112): the fused block must equal a
+    plain-torch evaluation that uses the very masks the kernels generate (hwgat_dropout_mask_f32) -- forward and
+    input gradient."""
     torch.manual_seed(5)
     B, F, K, d, nH, p = 2, 4, 32, 128, 2, 0.1
     hp = hw.HWGATEParams({"src_len": 8, "num_class": 3}, 2, DEV, num_kps=K)
@@ -195,9 +197,9 @@ def test_fused_dropout_matches_unfused_math_with_same_masks():
     from importlib import import_module
     fb = import_module("sl-hwgat_amd.block")
     x = torch.randn(B, F, K, d, device=DEV, requires_grad=True)
-    seeds = [11, 22, 33]
+    seeds = [11, 22, 33, 44]
     thr = torch.tensor([0.2], device=DEV)
-    out = fb.fused_block(x, thr, blk, model._mask_bits, nH, True, p, seeds)
+    out = fb.fused_block(x, thr, blk, model._mask_bits, nH, True, p, seeds, attn_p=attn_p)
     g = torch.randn_like(out)
     out.backward(g)
     gx = x.grad.clone()
@@ -212,7 +214,8 @@ def test_fused_dropout_matches_unfused_math_with_same_masks():
     m3 = HF.dropout_mask((B, F, K, d), seeds[2], p, DEV)
     tF = torch.nn.functional
     xn = tF.layer_norm(xr, (d,), blk.norm1.weight, blk.norm1.bias)
-    o = HF.window_attention(tF.linear(xn, blk.attn.qkv.weight, blk.attn.qkv.bias), model._mask_bits, thr, nH, True)
+    o = HF.window_attention(tF.linear(xn, blk.attn.qkv.weight, blk.attn.qkv.bias), model._mask_bits, thr, nH, True,
+                            drop=(seeds[3], attn_p))
     y = xr + tF.linear(o, blk.attn.proj.weight, blk.attn.proj.bias) * m1
     u = tF.gelu(tF.linear(tF.layer_norm(y, (d,), blk.norm2.weight, blk.norm2.bias), blk.ff.fc1.weight, blk.ff.fc1.bias)) * m2
     ref = y + tF.linear(u, blk.ff.fc2.weight, blk.ff.fc2.bias) * m3
@@ -221,6 +224,36 @@ def test_fused_dropout_matches_unfused_math_with_same_masks():
     assert rel_err(gx.cpu(), xr.grad.cpu()) < 1e-4
     for n, q in blk.named_parameters():
         assert rel_err(grads[n].cpu(), q.grad.cpu()) < 1e-4, n
+
+
+def test_model_with_attention_dropout_trains_and_eval_ignores_it():
+    """attn_drop_rate is a constructor hyper-parameter of the reference (HWGATE.py:273) that a user can turn on: a
+    model built with it runs train steps whose loss differs from the attn_drop_rate = 0 model on the same weights and
+    seeds, produces finite gradients for every parameter, and its eval forward is identical to the plain model's."""
+    torch.manual_seed(11)
+    K = 32
+    hp = hw.HWGATEParams({"src_len": 16, "num_class": 5}, 2, DEV, num_kps=K)
+    plain = hw.Model(*hp.get_model_params()).to(DEV)
+    hp.attn_drop_rate = 0.25
+    dropped = hw.Model(*hp.get_model_params()).to(DEV)
+    dropped.load_state_dict(plain.state_dict())
+    assert dropped.attn_drop_rate == 0.25 and plain.attn_drop_rate == 0.0
+    x = torch.randn(4, 16, K, 2, device=DEV)
+    plain.eval(); dropped.eval()
+    assert torch.equal(plain(x), dropped(x))
+    plain.train(); dropped.train()
+    losses = []
+    for m in (plain, dropped):
+        m._drop_calls = 7
+        torch.manual_seed(3)
+        out = m(x)
+        loss = out.float().logsumexp(-1).sum()
+        loss.backward()
+        losses.append(float(loss.detach()))
+        for n, q in m.named_parameters():
+            if q.requires_grad:
+                assert q.grad is not None and bool(torch.isfinite(q.grad).all()), n
+    assert abs(losses[0] - losses[1]) > 1e-6 * abs(losses[0])
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])

@@ -179,13 +179,31 @@ def test_sibling_mask_rows_on_cpu():
         HF.band_mask_rows(band, T + 1)
 
 
+def test_attention_dropout_is_a_constructor_hyper_parameter():
+    """reference HWGATE.py:273 `attn_drop_rate`: accepted by the HWGATE backend (stored, used in train mode only), range
+    checked; four site seeds per block (proj, fc1, fc2, attention); the sibling backends still refuse it"""
+    hp = hw.HWGATEParams({"src_len": 16, "num_class": 5}, 2, "cpu", num_kps=32)
+    hp.attn_drop_rate = 0.1
+    m = hw.Model(*hp.get_model_params())
+    assert m.attn_drop_rate == 0.1
+    assert len(m._seeds(0)) == 4 and len(set(m._seeds(0) + m._seeds(1))) == 8
+    hp.attn_drop_rate = 1.0
+    with pytest.raises(ValueError):
+        hw.Model(*hp.get_model_params())
+    with pytest.raises(ValueError):
+        hw.functional.window_attention(torch.zeros(1, 2, 16, 3 * 64), torch.zeros(2, 1, 32, dtype=torch.int32), None, 1, False,
+                                       drop=(1, 0.1))         # eval mode (no threshold) has no dropout
+    with pytest.raises(NotImplementedError):
+        hw.functional.attn_fwd("band", None, torch.zeros(1, 2, 16, 64), None, torch.zeros(1), 1, False, drop=(1, 0.1))
+
+
 def test_dropout_seeds_differ_per_rank_and_per_call():
     """data-parallel ranks share torch's seed but not dropout masks: rank_salt enters the site seeds"""
     hp = hw.HWGATEParams({"src_len": 32, "num_class": 5}, 2, torch.device("cpu"), num_kps=32)
     torch.manual_seed(1001)
     m = hw.Model(*hp.get_model_params())
     base = m._seeds(3)
-    assert len(set(base)) == 3 and m._seeds(3) == base and m._seeds(4) != base
+    assert len(set(base)) == 4 and m._seeds(3) == base and m._seeds(4) != base
     m.rank_salt = 1
     assert m._seeds(3) != base and len(set(m._seeds(3)) & set(base)) == 0
     m.rank_salt = 0
