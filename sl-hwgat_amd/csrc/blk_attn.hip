@@ -23,31 +23,10 @@
 // byte is 2 x (64/58)^2 higher (64-slot tiles for 58 tokens), so at head_dim 64 the backward pass sits
 // at the fp32 MFMA / HBM ridge rather than clearly HBM-bound (HGATE section).
 #include "attn_common.h"
+#include "blk_common.h"
 
 namespace {
-
-struct BlkGeom {
-    int F, KJ, nH, f, d, shift;
-};
-
-struct BUnit {
-    int64_t base[2];        // token index of joint 0 of frame A / frame B
-    int head, mrow;         // head index, first row of this unit's mask variant
-};
-__device__ __forceinline__ BUnit decode_bunit(const BlkGeom& g, int u) {
-    BUnit r;
-    const int n = u / g.nH;
-    r.head = u - n * g.nH;
-    const int fi = n % g.f;
-    const int b = n / g.f;
-    int fa = 2 * fi + g.shift, fb = fa + 1;          // torch.roll(x, -shift) (HGATE.py:186): shifted[t] = x[(t+shift) % F]
-    if (fa >= g.F) fa -= g.F;
-    if (fb >= g.F) fb -= g.F;
-    r.base[0] = ((int64_t)b * g.F + fa) * g.KJ;
-    r.base[1] = ((int64_t)b * g.F + fb) * g.KJ;
-    r.mrow = (g.shift && fi == g.f - 1) ? 64 : 0;    // the last shifted block straddles the clip ends (HGATE.py:158-172)
-    return r;
-}
+using namespace blk;
 
 // masks + softmax on one lane's 2 x 16 logits of one query row.
 // s[kt][r] = S[q][key slot kt*32 + crow(r,hh)] on entry, p = final probabilities on exit.
@@ -443,7 +422,13 @@ extern "C" int hwgat_blk_attn_bwd(const void* qkv, const void* dO, void* dqkv, c
         default: return launch_bbwd<T, 64>(qkv, dO, dqkv, maskbits, g, (int)units, st);           \
     }
     if (dtype == HWGAT_F32) { BWD(float) }
-    if (dtype == HWGAT_BF16) { BWD(bf16_t) }
+    if (dtype == HWGAT_BF16) {
+        // head_dim 64 (every HGATE stage): the 16x16-tile, four-waves-per-unit kernel of blk_attn_bf16.hip; the 32x32-tile
+        // form stays for head_dim 32 and as the lab A/B (HWGAT_BLK_B16=0)
+        static const bool old_b16 = lab_env("HWGAT_BLK_B16") && lab_env("HWGAT_BLK_B16")[0] == '0';
+        if (hd == 64 && !old_b16) return hwgat_launch_blk_bwd_b16(qkv, dO, dqkv, maskbits, B, F, KJ, nH, shifted, st);
+        BWD(bf16_t)
+    }
 #undef BWD
     return HWGAT_EDTYPE;
 }

@@ -92,6 +92,16 @@ def test_block_attention_edge_rows():
         out.sum().backward()
         assert rel_err(out.detach().cpu(), ref.detach()) < F32_TOL, shifted
         assert (x.grad.cpu() - ref_in.grad).abs().max() < 1e-5, shifted
+        # bf16 storage: the 16x16-tile backward (blk_attn_bf16.hip) has its own copy of the masks / fill / pad logic
+        xb = qkv.to(DEV, torch.bfloat16).requires_grad_(True)
+        refb_in = xb.detach().cpu().double().requires_grad_(True)
+        refb = _oracle_attn(refb_in, adj, nH, shifted)
+        refb.sum().backward()
+        outb = HF.block_attention(xb, bits, nH, shifted)
+        outb.sum().backward()
+        assert rel_err(outb.detach().float().cpu(), refb.detach()) < BF16_TOL, shifted
+        assert rel_err(xb.grad.float().cpu(), refb_in.grad) < BF16_TOL, shifted
+        assert bool(torch.isfinite(xb.grad).all())
     out = HF.block_attention(qkv.to(DEV), bits, nH, False).cpu()
     v = qkv[0, 0:2, :, 2 * d:].reshape(58, d)
     assert torch.allclose(out[0, 0, 3], v.mean(0), atol=1e-5)
@@ -146,6 +156,37 @@ def test_full_size_properties():
     g2 = torch.randn(B, F, KJ, d, device=DEV, generator=g)
     HF.block_attention(x, bits, nH, True).backward(g2)
     assert x.grad[..., :d].abs().max() < 1e-3
+
+
+def test_full_size_properties_bf16_backward():
+    """the bf16 backward on 16x16 tiles (blk_attn_bf16.hip) at the BASELINE batch: gradients do not depend on the batch
+    order (bit for bit), dV of an all-ones dO sums to the number of queries, k == const gives dq == 0, and one clip
+    against the dense fp64 oracle"""
+    B, F, KJ, nH, hd = 64, 128, 29, 2, 64
+    d = nH * hd
+    g = torch.Generator(device=DEV).manual_seed(2)
+    qkv = torch.randn(B, F, KJ, 3 * d, device=DEV, generator=g).to(torch.bfloat16)
+    do = torch.randn(B, F, KJ, d, device=DEV, generator=g).to(torch.bfloat16)
+    bits = HF.blk_mask_bits(OH.block_adjacency(), KJ).to(DEV)
+    for shifted in (False, True):
+        x = qkv.clone().requires_grad_(True)
+        HF.block_attention(x, bits, nH, shifted).backward(do)
+        perm = torch.randperm(B, device=DEV)
+        xp = qkv[perm].contiguous().requires_grad_(True)
+        HF.block_attention(xp, bits, nH, shifted).backward(do[perm].contiguous())
+        assert torch.equal(xp.grad, x.grad[perm])
+        ref_in = qkv[5:6].cpu().double().requires_grad_(True)
+        _oracle_attn(ref_in, OH.block_adjacency(), nH, shifted).backward(do[5:6].cpu().double())
+        assert rel_err(x.grad[5:6].float().cpu(), ref_in.grad) < BF16_TOL
+    x = qkv.clone().requires_grad_(True)
+    HF.block_attention(x, bits, nH, False).backward(torch.ones_like(do))
+    per_block = x.grad[..., 2 * d:].float().view(B, F // 2, 2 * KJ, d).sum(dim=2)    # dO == 1: dV sums to 58 (P rounded to bf16)
+    assert (per_block - 58).abs().max() < 0.5
+    x = qkv.clone()
+    x[..., d:2 * d] = 1.0                                                            # k == 1 -> dq = 0
+    x.requires_grad_(True)
+    HF.block_attention(x, bits, nH, True).backward(do)
+    assert x.grad[..., :d].float().abs().max() < 2e-2
 
 
 # ------------------------------------------------------------------------------------------ whole model
