@@ -5,6 +5,9 @@ python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "default r
 HWGAT_FORCE_DIST=1 python bench.py --no-cpu-baseline --no-secondary > $O/bench_force_dist.json 2> $O/bench_force_dist.err; echo "force_dist rc $?"
 python bench.py --config 3 --no-cpu-baseline > $O/bench_config3.json 2> $O/bench_config3.err; echo "c3 rc $?"
 python bench.py --from-host --no-cpu-baseline --no-secondary > $O/bench_from_host.json 2> $O/bench_from_host.err; echo "from_host rc $?"
+for m in wgate hgate; do for dt in bf16 f32; do
+  python bench.py --model $m --dtype $dt --no-cpu-baseline > $O/bench_${m}_${dt}.json 2> $O/bench_${m}_${dt}.err; echo "$m $dt rc $?"
+done; done
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d /tmp/prof_f32 -o f32 --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-secondary --steps 10 > $GRAFT_REPO_ROOT/$O/bench_under_rocprof_f32.json 2>/dev/null; echo "rocprof f32 rc $?"
 cp /tmp/prof_f32/f32_kernel_stats.csv $GRAFT_REPO_ROOT/$O/f32_kernel_stats.csv
