@@ -461,8 +461,11 @@ def main():
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary.config3_bf16 measurement the default run appends (same process, after the headline)")
     ap.add_argument("--no-kernel-timers", action="store_true", help="skip the per-launch HIP events (A/B runs)")
-    ap.add_argument("--timer-every", type=int, default=4,
-                    help="record the per-launch HIP events on every N-th step of the timed region (1 = every step)")
+    ap.add_argument("--timer-every", type=int, default=10,
+                    help="record the per-launch HIP events on every N-th step of the timed region (1 = every step).  The "
+                         "events cost host time (two records per launch, ~400 launches per step): nothing at the 102 ms "
+                         "headline step, but the 10-17 ms sibling-model steps are close to host-bound and a timed step "
+                         "runs 1.3-2.3x longer, so the default times 2 of 20 steps")
     ap.add_argument("--eval-mode", action="store_true", help="deterministic fwd+bwd (no dropout / attention drop)")
     ap.add_argument("--from-host", action="store_true",
                     help="feed every step from host samples through collate.PinnedBatcher (pinned staging + async H2D): "
@@ -557,8 +560,20 @@ def main():
         run_step()
     barrier()
     # per-launch HIP events (kernel durations for the roofline objects) are recorded on every `--timer-every`-th step
-    # of the timed region, not on all of them: an event pair costs ~3 us of stream time and a step has ~190 launches
+    # of the timed region, not on all of them: an event pair costs ~3 us of stream time and 5-10 us of host time, and a
+    # step has ~190-400 launches
     store, n_timed = {}, 0
+    if not args.no_kernel_timers:
+        # one untimed step with the events on counts the launches of a step; the events the timed region will use are then
+        # created BEFORE it (event creation, not recording, was most of what the per-launch timing cost)
+        probe = {}
+        HF.TIMERS = probe
+        run_step()
+        HF.TIMERS = None
+        per_step = 2 * sum(len(v) for v in probe.values())
+        HF.prime_events(per_step * (-(-args.steps // max(1, args.timer_every)) + 1))
+        del probe
+    barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         on = not args.no_kernel_timers and i % max(1, args.timer_every) == 0

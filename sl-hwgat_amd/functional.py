@@ -13,12 +13,24 @@ from ._lib import ptr, stream, dtype_code
 # is bracketed by HIP events recorded on the stream the kernel is launched on
 # (torch's current stream) and the (start, stop) pairs are appended per entry point.
 TIMERS = None
+_EVENTS = []            # events created (and recorded once, which is what makes the driver allocate them) ahead of a timed region
+
+
+def prime_events(n):
+    """create `n` timing events now: hipEventCreate happens on an event's first record, ~15 us each -- inside a timed
+    region that was 14 % of a 11 ms step (HGATE bf16), although the kernels themselves are untouched by it"""
+    fresh = [torch.cuda.Event(enable_timing=True) for _ in range(max(0, n - len(_EVENTS)))]
+    for e in fresh:
+        e.record()
+    torch.cuda.synchronize()
+    _EVENTS.extend(fresh)
 
 
 def call(name, *args):
     if TIMERS is None:
         return _lib.call(name, *args)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0 = _EVENTS.pop() if _EVENTS else torch.cuda.Event(enable_timing=True)
+    e1 = _EVENTS.pop() if _EVENTS else torch.cuda.Event(enable_timing=True)
     e0.record()
     _lib.call(name, *args)
     e1.record()
