@@ -222,20 +222,30 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8w_bf16_k(TnArgsB p, float* __r
     }
 }
 
-// dW tile += the slabs of its M splits, in split order.  One thread per 16-byte slab slot: slot = ((wave*8 + a)*4 + c)*64 + lane.
+// dW tile += the slabs of its M splits, in split order.  One thread per slab float (a tile = 65 536 floats = 256 blocks: with
+// one 16-byte slot per thread a single-tile launch had 64 blocks and read its 64 MB at a quarter of the chip's bandwidth):
+// float idx of a slab = (((wave*8 + a)*4 + c)*64 + lane)*4 + r.
 __global__ __launch_bounds__(256) void dw_reduce_k(const float* __restrict__ ws, float* __restrict__ dW, int n_split,
                                                    int n_tiles, int tiles_k, int K) {
-    const int tile = blockIdx.x >> 6;
-    const int slot = (blockIdx.x & 63) * 256 + threadIdx.x;
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    const float* src = ws + ((int64_t)tile * 16384 + slot) * 4;
-    for (int sp = 0; sp < n_split; ++sp) s += *reinterpret_cast<const f32x4*>(src + (int64_t)sp * n_tiles * 65536);
+    const int tile = blockIdx.x >> 8;
+    const int idx = (blockIdx.x & 255) * 256 + threadIdx.x;
+    const float* src = ws + (int64_t)tile * 65536 + idx;
+    const int64_t step = (int64_t)n_tiles * 65536;
+    float s = 0.f;
+    int sp = 0;
+    for (; sp + 8 <= n_split; sp += 8) {                       // eight loads in flight, added in split order
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = src[(sp + j) * step];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += v[j];
+    }
+    for (; sp < n_split; ++sp) s += src[sp * step];
+    const int r = idx & 3, slot = idx >> 2;
     const int lane = slot & 63, c = (slot >> 6) & 3, a = (slot >> 8) & 7, wave = slot >> 11;
     const int gm = wave >> 2, wk = wave & 3, fr = lane & 15, fq = lane >> 4;
     const int n0 = (tile / tiles_k) * BT, k0 = (tile % tiles_k) * BT;
-    float* dst = dW + (int64_t)(n0 + gm * 128 + a * 16 + fq * 4) * K + k0 + wk * 64 + c * 16 + fr;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) dst[(int64_t)r * K] += s[r];
+    dW[(int64_t)(n0 + gm * 128 + a * 16 + fq * 4 + r) * K + k0 + wk * 64 + c * 16 + fr] += s;
 }
 
 }  // namespace
@@ -269,7 +279,7 @@ int hwgat_launch_tn8w_bf16(TnArgsB a, hipStream_t st, float* ws) {
     const int grid = ((a.n_split + 7) / 8) * 8 * n_tiles;
     if (ws) {
         gemm_tn8w_bf16_k<true><<<grid, 512, 0, st>>>(a, ws);
-        dw_reduce_k<<<n_tiles * 64, 256, 0, st>>>(ws, a.dW, a.n_split, n_tiles, a.K / BT, a.K);
+        dw_reduce_k<<<n_tiles * 256, 256, 0, st>>>(ws, a.dW, a.n_split, n_tiles, a.K / BT, a.K);
     } else {
         gemm_tn8w_bf16_k<false><<<grid, 512, 0, st>>>(a, nullptr);
     }
