@@ -296,6 +296,20 @@ int hwgat_linear_tn_bf16_ws(const void* A, const void* B, float* dW, float* db, 
 /* out[C,R] = in[R,C]^T (used on weights only) */
 int hwgat_transpose_f32(const float* in, float* out, int R, int C, void* stream);
 
+/* ---- per-step weight preparation: ONE launch makes every derived copy of the fp32 master weights the fused linears
+ * consume, for all blocks of a model (no reference counterpart: operands of the kernels above).  `table` is an array of
+ * `n` entries in DEVICE memory, sorted by first_block; entry i owns workgroups [first_block, next entry's first_block):
+ *   op 0 copy:       out[N][K] = (dtype) W[N][K]                    ceil(N/32) * ceil(K/32) workgroups
+ *   op 1 transpose:  out[K][N] = (dtype) W[N][K]^T                  ceil(N/32) * ceil(K/32) workgroups
+ *   op 2 LN fold:    out = W o gamma (dtype), s[N], c[N] exactly as hwgat_ln_fold (bias may be NULL)   ceil(N/4) workgroups
+ * total_blocks = the sum of the entries' workgroups; dtype = HWGAT_F32 | HWGAT_BF16 of every `out`. */
+typedef struct {
+    const float* W; const float* bias; const float* gamma; const float* beta;
+    void* out; float* s; float* c;
+    int32_t N, K, op, first_block;
+} hwgat_prep_entry;
+int hwgat_weight_prep(const hwgat_prep_entry* table, int n, int total_blocks, int dtype, void* stream);
+
 /* the dropout mask the fused kernels use: out[i] = keep(seed, i) ? 1/(1-p) : 0 */
 int hwgat_dropout_mask_f32(float* out, int64_t n, uint32_t seed, float p, void* stream);
 

@@ -31,6 +31,7 @@ _SIGS = {
     "hwgat_ln_bwd_xn": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _U, _F, _P, _P],
     "hwgat_win_attn_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "hwgat_win_attn_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "hwgat_weight_prep": [_P, _I, _I, _I, _P],
     "hwgat_win_attn_fwd_drop": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _U, _F, _P],
     "hwgat_win_attn_bwd_drop": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _U, _F, _P],
     "hwgat_blk_attn_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],

@@ -412,6 +412,95 @@ class CarryBook:
         return rec is not None and rec == (dout.data_ptr(), dout._version, tuple(dout.shape))
 
 
+class WeightPrep:
+    """Every derived copy of the block weights a forward (+ backward) call consumes, made by ONE launch
+    (hwgat_weight_prep): per block the LayerNorm-folded qkv / fc1 weights with their row sums (hwgat_ln_fold), the
+    activation-dtype copies of proj / fc2 (bf16 activations only) and, when a backward will follow, the four transposed
+    copies for the dX launches.  The output buffers and the device table are built once per (model, dtype, train) and
+    reused: the copies are rewritten by every forward call from the current master weights, and a backward reads the
+    copies of its own forward (the weights do not change in between).  `per_block[k]` maps names to tensors."""
+
+    OP_COPY, OP_T, OP_FOLD = 0, 1, 2
+
+    def __init__(self, blocks, dtype, with_transposes):
+        import ctypes
+        import numpy as np
+        self.dtype = dtype
+        dev = blocks[0].attn.qkv.weight.device
+        ent, self.per_block, self._keep = [], [], []
+        first = 0
+
+        def add(op, W, out, bias=None, gamma=None, beta=None, s=None, c=None):
+            nonlocal first
+            N, K = W.shape
+            ent.append((W.data_ptr(), 0 if bias is None else bias.data_ptr(), 0 if gamma is None else gamma.data_ptr(),
+                        0 if beta is None else beta.data_ptr(), out.data_ptr(), 0 if s is None else s.data_ptr(),
+                        0 if c is None else c.data_ptr(), N, K, op, first))
+            first += -(-N // 4) if op == self.OP_FOLD else (-(-N // 32)) * (-(-K // 32))
+
+        def fold(lin, norm):
+            N, K = lin.weight.shape
+            Wf = torch.empty(N, K, device=dev, dtype=dtype)
+            sc = torch.empty(2, N, device=dev, dtype=torch.float32)
+            add(self.OP_FOLD, lin.weight, Wf, lin.bias, norm.weight, norm.bias, sc[0], sc[1])
+            return Wf, sc[0], sc[1]
+
+        def copy(W, transposed):
+            N, K = W.shape
+            out = torch.empty((K, N) if transposed else (N, K), device=dev, dtype=dtype)
+            add(self.OP_T if transposed else self.OP_COPY, W, out)
+            return out
+
+        srcs = []
+        for blk in blocks:
+            lins = (blk.attn.qkv, blk.attn.proj, blk.ff.fc1, blk.ff.fc2)
+            srcs += [t for lin in lins for t in (lin.weight, lin.bias)] + [blk.norm1.weight, blk.norm1.bias, blk.norm2.weight, blk.norm2.bias]
+            d = {"qkv_f": fold(blk.attn.qkv, blk.norm1), "w1_f": fold(blk.ff.fc1, blk.norm2)}
+            if dtype != torch.float32:
+                d["wp_c"], d["w2_c"] = copy(blk.attn.proj.weight, False), copy(blk.ff.fc2.weight, False)
+            if with_transposes:
+                d["wqkvT"], d["wpT"] = copy(blk.attn.qkv.weight, True), copy(blk.attn.proj.weight, True)
+                d["w1T"], d["w2T"] = copy(blk.ff.fc1.weight, True), copy(blk.ff.fc2.weight, True)
+            self.per_block.append(d)
+        self.key = self.signature(blocks, dtype, with_transposes)
+        rec = np.dtype([("p", np.uint64, 7), ("i", np.int32, 4)])           # hwgat_prep_entry: 7 pointers, N, K, op, first_block
+        assert rec.itemsize == 72
+        host = np.zeros(len(ent), dtype=rec)
+        for i, e in enumerate(ent):
+            host[i]["p"] = e[:7]
+            host[i]["i"] = e[7:]
+        self.table = torch.from_numpy(host.view(np.uint8).copy()).to(dev)
+        self.n, self.total = len(ent), first
+
+    @staticmethod
+    def signature(blocks, dtype, with_transposes):
+        """what the cached buffers and table were built for: the addresses of every source parameter"""
+        ptrs = []
+        for blk in blocks:
+            for t in (blk.attn.qkv.weight, blk.attn.qkv.bias, blk.attn.proj.weight, blk.ff.fc1.weight, blk.ff.fc1.bias,
+                      blk.ff.fc2.weight, blk.norm1.weight, blk.norm1.bias, blk.norm2.weight, blk.norm2.bias):
+                ptrs.append(t.data_ptr())
+        return (dtype, bool(with_transposes), tuple(ptrs))
+
+    def run(self):
+        call("hwgat_weight_prep", ptr(self.table), self.n, self.total, 0 if self.dtype == torch.float32 else 1, stream())
+        return self
+
+
+def weight_prep(owner, blocks, dtype, with_transposes):
+    """the (cached) WeightPrep of `owner` (a model) for this dtype / mode, run for the current weights; None where the
+    masters are not plain fp32 parameters (the per-call kernels then do the work, as before)"""
+    ws = [blk.attn.qkv.weight for blk in blocks]
+    if not ws or any(w.dtype != torch.float32 or not w.is_cuda for w in ws):
+        return None
+    key = WeightPrep.signature(blocks, dtype, with_transposes)
+    cache = owner.__dict__.setdefault("_weight_prep_cache", {})
+    wp = cache.get(key[:2])
+    if wp is None or wp.key != key:
+        wp = cache[key[:2]] = WeightPrep(blocks, dtype, with_transposes)
+    return wp.run()
+
+
 class HandOver:
     """What one block's epilogues produced for the next block of the same forward call: `of` = the tensor the values
     belong to, `stats` = (mean, rstd) of its rows (from the fc2 epilogue), `carrier` / `up` = the data-less carrier of
@@ -424,6 +513,7 @@ class HandOver:
         self.last_block = last_block
         self.deterministic = bool(deterministic)
         self.book = CarryBook()
+        self.prep = None            # WeightPrep of this call (per_block[k] = the derived weight copies of block k)
 
 
 EPI_BIAS, EPI_BIAS_DROP_RES, EPI_BIAS_GELU_DROP, EPI_GELU_BWD, EPI_NONE, EPI_BIAS_GELU_DROP_G, EPI_MUL_AUX = 0, 1, 2, 3, 4, 5, 6
@@ -484,14 +574,14 @@ def ln_fold(W, bias, gamma, beta, dtype):
     return Wf, sc[0], sc[1]
 
 
-def linear_nt_ln(A, W, bias, ln, *, epi=EPI_BIAS, epi_seed=0, epi_p=0.0, out=None):
+def linear_nt_ln(A, W, bias, ln, *, epi=EPI_BIAS, epi_seed=0, epi_p=0.0, out=None, folded=None):
     """LN(A) . W^T + bias with the epilogue `epi` (EPI_BIAS or EPI_BIAS_GELU_DROP); W, bias are the fp32 master
     parameters, ln = (mean, rstd, gamma, beta).  Whole-tile token counts take the folded form (no per-element
     normalisation in the GEMM's load path), anything else the normalising loader."""
     mean, rstd, gamma, beta = ln
     M = A.numel() // A.shape[-1]
     if LN_FOLD and M % 128 == 0 and W.dtype == torch.float32 and gamma.dtype == torch.float32:   # hwgat_ln_fold reads fp32 masters
-        Wf, s, c = ln_fold(W, bias, gamma, beta, A.dtype)
+        Wf, s, c = folded if folded is not None else ln_fold(W, bias, gamma, beta, A.dtype)   # `folded`: made by WeightPrep
         return linear_nt(A, Wf, None, pro=PRO_LN_FOLD, ln=(mean, rstd, s, c), epi=epi, epi_seed=epi_seed, epi_p=epi_p, out=out)
     Wc = W if W.dtype == A.dtype else W.to(A.dtype)
     return linear_nt(A, Wc, bias, pro=PRO_LN, ln=ln, epi=epi, epi_seed=epi_seed, epi_p=epi_p, out=out)

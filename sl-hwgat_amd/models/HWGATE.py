@@ -171,7 +171,8 @@ class Model(nn.Module):
                                   stats=have, want_stats=want, merge_out=merge, return_stats=True,
                                   carrier=carrier, up=up, carry_out=(want or k == hand.last_block) and not merge,
                                   return_carrier=True, book=hand.book, deterministic=hand.deterministic,
-                                  attn_p=self.attn_drop_rate if self.training else 0.0)
+                                  attn_p=self.attn_drop_rate if self.training else 0.0,
+                                  prep=hand.prep.per_block[k] if hand.prep is not None else None)
         hand.of, hand.stats, hand.carrier, hand.up = out, st, oc, ((seeds[2], p) if oc is not None else None)
         return out
 
@@ -194,6 +195,9 @@ class Model(nn.Module):
         h = self._embed(x)
         n_blocks = sum(len(st.blocks) for st in self.layers)
         hand = HF.HandOver(last_block=n_blocks - 1, deterministic=self.deterministic_eval and not self.training)
+        # every derived copy of the block weights this call needs (LayerNorm folds, bf16 copies, transposes for the backward)
+        hand.prep = HF.weight_prep(self, [blk for st in self.layers for blk in st.blocks], self.activation_dtype,
+                                   torch.is_grad_enabled())
         kk = 0
         for i, stage in enumerate(self.layers):          # every block but the last feeds a LayerNorm; stage ends merge
             for j in range(len(stage.blocks)):

@@ -226,6 +226,48 @@ def test_fused_dropout_matches_unfused_math_with_same_masks(attn_p):
         assert rel_err(grads[n].cpu(), q.grad.cpu()) < 1e-4, n
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_weight_prep_matches_the_per_call_kernels_and_follows_the_parameters(dtype):
+    """functional.WeightPrep (hwgat_weight_prep: every derived weight copy of a forward call in one launch) against the
+    per-call kernels it replaces -- hwgat_ln_fold, hwgat_transpose_f32 + cast, the dtype cast -- bit for bit; the cached
+    table is reused while the parameters stay where they are, sees in-place updates (an optimizer step) and is rebuilt
+    when a parameter is reallocated."""
+    HF = hw.functional
+    torch.manual_seed(3)
+    hp = hw.HWGATEParams({"src_len": 16, "num_class": 5}, 2, DEV, num_kps=32)
+    model = hw.Model(*hp.get_model_params()).to(DEV)
+    for q in model.parameters():
+        if q.requires_grad:
+            q.data.normal_(0, 0.3)
+    blocks = [blk for st in model.layers for blk in st.blocks]
+
+    def check(wp):
+        for blk, d in zip(blocks, wp.per_block):
+            for name, lin, norm in (("qkv_f", blk.attn.qkv, blk.norm1), ("w1_f", blk.ff.fc1, blk.norm2)):
+                ref = HF.ln_fold(lin.weight, lin.bias, norm.weight, norm.bias, dtype)
+                assert all(torch.equal(a, b) for a, b in zip(d[name], ref)), name
+            for name, w in (("wqkvT", blk.attn.qkv.weight), ("wpT", blk.attn.proj.weight), ("w1T", blk.ff.fc1.weight),
+                            ("w2T", blk.ff.fc2.weight)):
+                assert torch.equal(d[name], HF.transpose(w, dtype)), name
+            if dtype != torch.float32:
+                assert torch.equal(d["wp_c"], blk.attn.proj.weight.to(dtype)) and torch.equal(d["w2_c"], blk.ff.fc2.weight.to(dtype))
+            else:
+                assert "wp_c" not in d
+
+    wp = HF.weight_prep(model, blocks, dtype, True)
+    check(wp)
+    assert HF.weight_prep(model, blocks, dtype, True) is wp                       # cached
+    assert "w2T" not in HF.weight_prep(model, blocks, dtype, False).per_block[0]  # no backward: no transposes
+    with torch.no_grad():
+        blocks[1].ff.fc1.weight.mul_(1.5)                                         # in place: same table, new values
+    assert HF.weight_prep(model, blocks, dtype, True) is wp
+    check(wp)
+    blocks[0].attn.qkv.weight.data = blocks[0].attn.qkv.weight.data.clone() * 0.5  # reallocated: the table is rebuilt
+    wp2 = HF.weight_prep(model, blocks, dtype, True)
+    assert wp2 is not wp
+    check(wp2)
+
+
 def test_model_with_attention_dropout_trains_and_eval_ignores_it():
     """attn_drop_rate is a constructor hyper-parameter of the reference (HWGATE.py:273) that a user can turn on: a
     model built with it runs train steps whose loss differs from the attn_drop_rate = 0 model on the same weights and
