@@ -130,7 +130,7 @@ class _SaturatedCell:
     of the timed steps / (last end - first start).  One 16-thread process leaves a 128-core host ~8x under-used; this is
     the CPU's best."""
 
-    def __init__(self, c, K, phys, usable, threads=None, steps=3, max_proc=4):
+    def __init__(self, c, K, phys, usable, threads=None, steps=2, max_proc=4):
         import multiprocessing as mp
         cores = min(phys, usable)
         self.n_proc = min(max_proc, max(1, cores // (threads or 16)))
@@ -171,12 +171,15 @@ class _SaturatedCell:
             for p in self.procs:
                 p.join(timeout=5)
         ok = [g for g in got if g[1] is not None]
-        if len(ok) != self.n_proc:
+        if 2 * len(ok) < self.n_proc:
             return {"error": f"{len(ok)} of {self.n_proc} workers finished within {limit_s:.0f} s",
                     "details": [str(g[3]) for g in got if g[1] is None][:2]}
+        # (workers that did not finish in time still loaded the host while the others were timed: the rate of the finished
+        # ones, scaled to all processes, is the aggregate a longer wait would have measured)
         span = max(g[2] for g in ok) - min(g[1] for g in ok)
-        return {"clips_per_s": round(sum(g[3] for g in ok) / span, 3), "processes": self.n_proc,
-                "threads_per_process": self.threads, "timed_steps": self.steps, "seconds": round(time.perf_counter() - t_begin, 1)}
+        return {"clips_per_s": round(sum(g[3] for g in ok) / span * self.n_proc / len(ok), 3), "processes": self.n_proc,
+                "finished": len(ok), "threads_per_process": self.threads, "timed_steps": self.steps,
+                "seconds": round(time.perf_counter() - t_begin, 1)}
 
 
 def cpu_baseline_saturated(c, K, phys, usable, threads=None, steps=3, limit_s=40.0, max_proc=4):
@@ -264,7 +267,7 @@ def cpu_baseline(hgate=False, budget_s=45.0):
     value, cores = cells[best]["clips_per_s"], threads
     saturated = None
     if not hgate:
-        saturated = sat_cell.run(limit_s=40.0)
+        saturated = sat_cell.run(limit_s=50.0)
         if saturated and saturated.get("clips_per_s", 0.0) > value:
             value, cores, best = saturated["clips_per_s"], saturated["processes"] * saturated["threads_per_process"], "host_saturated_eval_B2"
     return {"value": value, "unit": "clips/s", "cores": cores, "kind": "port",
