@@ -303,7 +303,7 @@ def visible_gpu_count():
     return n
 
 
-def secondary_config3(hw, train_mod, dev, steps=10, warmup=3):
+def secondary_config3(hw, train_mod, dev, steps=10, warmup=6):
     """BASELINE configs[2] (the headline shape with bf16 activations / bf16 MFMA linears, the HBM-bound variant) measured
     in the SAME process right after the headline, so that every driver run of the default `python bench.py` also
     records it: same full train step (zero_grad + fwd + loss + bwd + fused AdamW), train mode, inputs resident in HBM.

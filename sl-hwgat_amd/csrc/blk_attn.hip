@@ -402,7 +402,11 @@ extern "C" int hwgat_blk_attn_fwd(const void* qkv, void* o, const uint32_t* mask
         default: return launch_bfwd<T, 64>(qkv, o, maskbits, g, (int)units, st);            \
     }
     if (dtype == HWGAT_F32) { FWD(float) }
-    if (dtype == HWGAT_BF16) { FWD(bf16_t) }
+    if (dtype == HWGAT_BF16) {
+        static const bool old_b16 = lab_env("HWGAT_BLK_B16") && lab_env("HWGAT_BLK_B16")[0] == '0';     // see hwgat_blk_attn_bwd
+        if (hd == 64 && !old_b16) return hwgat_launch_blk_fwd_b16(qkv, o, maskbits, B, F, KJ, nH, shifted, st);
+        FWD(bf16_t)
+    }
 #undef FWD
     return HWGAT_EDTYPE;
 }

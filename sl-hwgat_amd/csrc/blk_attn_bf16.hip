@@ -1,6 +1,6 @@
-// HGATE block graph-attention backward, bf16 storage, head_dim 64, on gfx950 (MI355X).
+// HGATE block graph-attention, bf16 storage, head_dim 64, on gfx950 (MI355X): forward and backward.
 //
-// Same contract as blk_attn_bwd_k (blk_attn.hip: MSA.forward's attention core of the reference's
+// Same contract as blk_attn_fwd_k / blk_attn_bwd_k (blk_attn.hip: MSA.forward's attention core of the reference's
 // hwgat/models/HGATE.py:84-108 differentiated, with block_partition / block_reverse / torch.roll, HGATE.py:30-47,184-207,
 // as index arithmetic).  The 32x32-tile kernel there needs 288 registers per wave for a unit (its 2 x 16 scores, their
 // probabilities and gradients per lane, 32-row B-side fragments assembled with v_perm) and reaches 0.29 - 0.37 of the HBM
@@ -72,6 +72,125 @@ __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" :
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_barrier" ::: "memory"); }
 __device__ __forceinline__ void wait_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// row operand (16 bytes: channels 32 kc + 8 g .. + 7) of slot row `row`, k-step kc
+__device__ __forceinline__ u32x4v row_op(const char* img, int row, int kc, int gq) {
+    return *(const lds_u32x4*)(img + chunk_off(row, 4 * kc + gq));
+}
+// column operand over the 32 slot rows of half h (k = slot 32 h + 16 (e >> 2) + 4 g + (e & 3)), channels 16 ct + (l & 15)
+__device__ __forceinline__ u32x4v col_op(const char* img, int h, int ct, int lr, int gq) {
+    const int r0 = 32 * h + 4 * gq + (lr >> 2), c = 2 * ct + ((lr & 3) >> 1), half = (lr & 1) * 8;
+    const u32x2v lo = __builtin_bit_cast(u32x2v, __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + chunk_off(r0, c) + half)));
+    const u32x2v hi = __builtin_bit_cast(u32x2v, __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + chunk_off(r0 + 16, c) + half)));
+    return u32x4v{lo.x, lo.y, hi.x, hi.y};
+}
+
+// masks (HGATE.py:96-104) + the "== 0 -> -10000" fill + softmax numerators over the 64 key slots of one query; pad key slots
+// are no keys at all.  s[kt][r] = raw score of key slot 16 kt + 4g + r on entry, exp(scaled, masked score - row max) on
+// exit; returns the row sum, `nz` = bit 4 kt + r set where the logit was kept (the gradient flows).
+__device__ __forceinline__ float masked_exp64(f32x4v (&s)[4], uint32_t mb0, uint32_t mb1, int gq, int KJ, uint32_t& nz) {
+    nz = 0;
+    float m = -3.0e38f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = 16 * (kt & 1) + 4 * gq + r;
+            const bool vis = ((kt >> 1 ? mb1 : mb0) >> j) & 1u;
+            float v = vis ? s[kt][r] * SCALE : 0.f;
+            if (v == 0.f) v = -10000.f; else nz |= 1u << (4 * kt + r);          // HGATE.py:104
+            if (j >= KJ) { v = -3.0e38f; nz &= ~(1u << (4 * kt + r)); }
+            s[kt][r] = v;
+            m = __builtin_fmaxf(m, v);
+        }
+    m = xg_max(m);
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            s[kt][r] = __builtin_amdgcn_exp2f((s[kt][r] - m) * LOG2E);
+            sum += s[kt][r];
+        }
+    return xg_sum(sum);
+}
+
+// ---- stage: wave w issues DMA instructions 2w, 2w+1 (8 slot rows each) of each image: Q, K, V (and dO with NIMG = 4)
+template <int NIMG>
+__device__ __forceinline__ void stage_unit(char* sm, const bf16_t* qkv, const bf16_t* dO, const BlkGeom& g, const BUnit& un,
+                                           int64_t qkv_bytes, int64_t do_bytes, int lane, int w) {
+    const int64_t rs = 3 * (int64_t)g.d;
+    const uint32_t rs2 = (uint32_t)rs * 2, d2 = (uint32_t)g.d * 2;
+    const int64_t t0 = min(un.base[0], un.base[1]);              // (a shifted block that wraps has frame B in front of frame A)
+    const bf16_t* qb = qkv + t0 * rs + un.head * HD;
+    const int span_q = (int)min(qkv_bytes - ((const char*)qb - (const char*)qkv), (int64_t)0x7fffffff);
+    const auto rq = __builtin_amdgcn_make_buffer_rsrc((void*)qb, 0, span_q, 0x00020000);
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const int ins = 2 * w + jj;                              // slot rows 8 ins .. 8 ins + 7
+        const int row = 8 * ins + (lane >> 3), cp = lane & 7;
+        const int joint = min(row & 31, g.KJ - 1);               // pad slots re-read the last joint (finite data, masked later)
+        const uint32_t frame_rel = (uint32_t)((ins >> 2 ? un.base[1] : un.base[0]) - t0);
+        const uint32_t src = (uint32_t)(cp ^ xr(row)) << 4;
+        const int vq = (int)((frame_rel + joint) * rs2 + src);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (lds_void)(sm + ins * 1024), 16, vq, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (lds_void)(sm + IMG + ins * 1024), 16, vq, (int)d2, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (lds_void)(sm + 2 * IMG + ins * 1024), 16, vq, (int)(2 * d2), 0, 0);
+        if constexpr (NIMG == 4) {
+            const bf16_t* gb = dO + t0 * (int64_t)g.d + un.head * HD;
+            const int span_g = (int)min(do_bytes - ((const char*)gb - (const char*)dO), (int64_t)0x7fffffff);
+            const auto rg = __builtin_amdgcn_make_buffer_rsrc((void*)gb, 0, span_g, 0x00020000);
+            const int vg = (int)((frame_rel + joint) * d2 + src);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_void)(sm + 3 * IMG + ins * 1024), 16, vg, 0, 0, 0);
+        }
+    }
+}
+
+// =============================================================== forward
+// wave w owns query slots 16w .. 16w+15: S^T = K Q^T, masks + softmax, O^T = V^T P^T (V as a column operand), O rows scaled
+// by 1 / row sum and stored as four consecutive channels per lane.  24 KB of LDS: six workgroups per CU.
+__global__ __launch_bounds__(256, 4) void blk_fwd_b16_k(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
+                                                        const uint32_t* __restrict__ maskbits, BlkGeom g, int64_t qkv_bytes) {
+    __shared__ __attribute__((aligned(1024))) char sm[3 * IMG];  // Q | K | V
+    const char* Qt = sm;
+    const char* Kt = sm + IMG;
+    const char* Vt = sm + 2 * IMG;
+    const int lane = threadIdx.x & 63, lr = lane & 15, gq = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const BUnit un = decode_bunit(g, blockIdx.x);
+    stage_unit<3>(sm, qkv, nullptr, g, un, qkv_bytes, 0, lane, w);
+    const int slot = 16 * w + lr;
+    const bool real = (slot & 31) < g.KJ;
+    const int64_t tok = (w >> 1 ? un.base[1] : un.base[0]) + min(slot & 31, g.KJ - 1);
+    const uint32_t mb0 = maskbits[(un.mrow + slot) * 2], mb1 = maskbits[(un.mrow + slot) * 2 + 1];
+    wait_vm0();
+    wg_barrier();
+
+    f32x4v s[4];
+    {
+        const u32x4v q0 = row_op(Qt, slot, 0, gq), q1 = row_op(Qt, slot, 1, gq);
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const f32x4v z = {0.f, 0.f, 0.f, 0.f};
+            s[kt] = mfma32(row_op(Kt, 16 * kt + lr, 1, gq), q1, mfma32(row_op(Kt, 16 * kt + lr, 0, gq), q0, z));
+        }
+    }
+    uint32_t nz;
+    const float inv = __builtin_amdgcn_rcpf(masked_exp64(s, mb0, mb1, gq, g.KJ, nz));
+    u32x2v pb[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) pb[kt] = to_bf(s[kt]);       // numerators, rounded to bf16 as MFMA operands
+    bf16_t* row = o + tok * (int64_t)g.d + un.head * HD + 4 * gq;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {                             // (products outside any lane-dependent branch: transposed reads
+        f32x4v acc = {0.f, 0.f, 0.f, 0.f};                       //  and MFMAs want all lanes)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            acc = mfma32(col_op(Vt, h, ct, lr, gq), u32x4v{pb[2 * h].x, pb[2 * h].y, pb[2 * h + 1].x, pb[2 * h + 1].y}, acc);
+        if (real) *reinterpret_cast<u32x2v*>(row + 16 * ct) = to_bf(acc * inv);  // lane (q, g), register r -> channel 16 ct + 4g + r
+    }
+}
+
+// =============================================================== backward
 __global__ __launch_bounds__(256, 3) void blk_bwd_b16_k(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
                                                         bf16_t* __restrict__ dqkv, const uint32_t* __restrict__ maskbits,
                                                         BlkGeom g, int64_t qkv_bytes, int64_t do_bytes) {
@@ -88,29 +207,7 @@ __global__ __launch_bounds__(256, 3) void blk_bwd_b16_k(const bf16_t* __restrict
     const int64_t rs = 3 * (int64_t)g.d;                         // qkv row stride (elements)
     const uint32_t rs2 = (uint32_t)rs * 2, d2 = (uint32_t)g.d * 2;
 
-    // ---- stage: wave w issues DMA instructions 2w, 2w+1 (8 slot rows each) of each of the four images
-    {
-        const int64_t t0 = min(un.base[0], un.base[1]);          // (a shifted block that wraps has frame B in front of frame A)
-        const bf16_t* qb = qkv + t0 * rs + un.head * HD;
-        const bf16_t* gb = dO + t0 * (int64_t)g.d + un.head * HD;
-        const int span_q = (int)min(qkv_bytes - ((const char*)qb - (const char*)qkv), (int64_t)0x7fffffff);
-        const int span_g = (int)min(do_bytes - ((const char*)gb - (const char*)dO), (int64_t)0x7fffffff);
-        const auto rq = __builtin_amdgcn_make_buffer_rsrc((void*)qb, 0, span_q, 0x00020000);
-        const auto rg = __builtin_amdgcn_make_buffer_rsrc((void*)gb, 0, span_g, 0x00020000);
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-            const int ins = 2 * w + jj;                          // slot rows 8 ins .. 8 ins + 7
-            const int row = 8 * ins + (lane >> 3), cp = lane & 7;
-            const int joint = min(row & 31, g.KJ - 1);           // pad slots re-read the last joint (finite data, masked below)
-            const uint32_t frame_rel = (uint32_t)((ins >> 2 ? un.base[1] : un.base[0]) - t0);
-            const uint32_t src = (uint32_t)(cp ^ xr(row)) << 4;
-            const int vq = (int)((frame_rel + joint) * rs2 + src), vg = (int)((frame_rel + joint) * d2 + src);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (lds_void)(Qt + ins * 1024), 16, vq, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (lds_void)(Kt + ins * 1024), 16, vq, (int)d2, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (lds_void)(Vt + ins * 1024), 16, vq, (int)(2 * d2), 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_void)(Gt + ins * 1024), 16, vg, 0, 0, 0);
-        }
-    }
+    stage_unit<4>(sm, qkv, dO, g, un, qkv_bytes, do_bytes, lane, w);
     // this lane's query slot in phase A / key slot in phase B, and the mask words of the query
     const int slot = 16 * w + lr;
     const bool real = (slot & 31) < g.KJ;
@@ -119,55 +216,21 @@ __global__ __launch_bounds__(256, 3) void blk_bwd_b16_k(const bf16_t* __restrict
     wait_vm0();
     wg_barrier();
 
-    // row operand (16 bytes: channels 32 kc + 8 g .. + 7) of slot row `row`, k-step kc
-    auto row_op = [&](const char* img, int row, int kc) {
-        return *(const lds_u32x4*)(img + chunk_off(row, 4 * kc + gq));
-    };
-    // column operand over the 32 slot rows of half h (k = slot 32 h + 16 (e >> 2) + 4 g + (e & 3)), channels 16 ct + (l & 15)
-    auto col_op = [&](const char* img, int h, int ct) {
-        const int r0 = 32 * h + 4 * gq + (lr >> 2), c = 2 * ct + ((lr & 3) >> 1), half = (lr & 1) * 8;
-        const u32x2v lo = __builtin_bit_cast(u32x2v, __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + chunk_off(r0, c) + half)));
-        const u32x2v hi = __builtin_bit_cast(u32x2v, __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + chunk_off(r0 + 16, c) + half)));
-        return u32x4v{lo.x, lo.y, hi.x, hi.y};
-    };
-
     // ================================================= phase A: query slot `slot`
     f32x4v s[4], dp[4];
     {
-        const u32x4v q0 = row_op(Qt, slot, 0), q1 = row_op(Qt, slot, 1);
-        const u32x4v g0 = row_op(Gt, slot, 0), g1 = row_op(Gt, slot, 1);
+        const u32x4v q0 = row_op(Qt, slot, 0, gq), q1 = row_op(Qt, slot, 1, gq);
+        const u32x4v g0 = row_op(Gt, slot, 0, gq), g1 = row_op(Gt, slot, 1, gq);
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
             const f32x4v z = {0.f, 0.f, 0.f, 0.f};
-            s[kt] = mfma32(row_op(Kt, 16 * kt + lr, 1), q1, mfma32(row_op(Kt, 16 * kt + lr, 0), q0, z));     // S[q][key 16 kt + 4g + r]
-            dp[kt] = mfma32(row_op(Vt, 16 * kt + lr, 1), g1, mfma32(row_op(Vt, 16 * kt + lr, 0), g0, z));    // dP[q][key]
+            s[kt] = mfma32(row_op(Kt, 16 * kt + lr, 1, gq), q1, mfma32(row_op(Kt, 16 * kt + lr, 0, gq), q0, z));     // S[q][key 16 kt + 4g + r]
+            dp[kt] = mfma32(row_op(Vt, 16 * kt + lr, 1, gq), g1, mfma32(row_op(Vt, 16 * kt + lr, 0, gq), g0, z));    // dP[q][key]
         }
     }
-    // masks (HGATE.py:96-104) + softmax over the 64 key slots; pad key slots are no keys at all
-    uint32_t nz = 0;
-    float m = -3.0e38f;
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int j = 16 * (kt & 1) + 4 * gq + r;
-            const bool vis = ((kt >> 1 ? mb1 : mb0) >> j) & 1u;
-            float v = vis ? s[kt][r] * SCALE : 0.f;
-            if (v == 0.f) v = -10000.f; else nz |= 1u << (4 * kt + r);          // HGATE.py:104
-            if (j >= g.KJ) { v = -3.0e38f; nz &= ~(1u << (4 * kt + r)); }
-            s[kt][r] = v;
-            m = __builtin_fmaxf(m, v);
-        }
-    m = xg_max(m);
-    float sum = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            s[kt][r] = __builtin_amdgcn_exp2f((s[kt][r] - m) * LOG2E);
-            sum += s[kt][r];
-        }
-    const float inv = real ? __builtin_amdgcn_rcpf(xg_sum(sum)) : 0.f;          // pad query slots: P = dS = 0
+    uint32_t nz;
+    const float sum = masked_exp64(s, mb0, mb1, gq, g.KJ, nz);
+    const float inv = real ? __builtin_amdgcn_rcpf(sum) : 0.f;          // pad query slots: P = dS = 0
     float delta = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
@@ -196,7 +259,7 @@ __global__ __launch_bounds__(256, 3) void blk_bwd_b16_k(const bf16_t* __restrict
             acc[ct] = f32x4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int h = 0; h < 2; ++h)
-                acc[ct] = mfma32(col_op(Kt, h, ct), u32x4v{db[2 * h].x, db[2 * h].y, db[2 * h + 1].x, db[2 * h + 1].y}, acc[ct]);
+                acc[ct] = mfma32(col_op(Kt, h, ct, lr, gq), u32x4v{db[2 * h].x, db[2 * h].y, db[2 * h + 1].x, db[2 * h + 1].y}, acc[ct]);
         }
         if (real) {
             bf16_t* row = dqkv + tok * rs + un.head * HD + 4 * gq;
@@ -215,11 +278,11 @@ __global__ __launch_bounds__(256, 3) void blk_bwd_b16_k(const bf16_t* __restrict
         for (int h = 0; h < 2; ++h) {
             // B operand: element e of lane (key = 16 w + lr, g) = X[query 32 h + 16 (e >> 2) + 4g + (e & 3)][key]: the column
             // operand pattern on the [query][key] images, "channel chunk" = key group w
-            const u32x4v d2 = col_op(Dt, h, w), p2 = col_op(Pt, h, w);
+            const u32x4v d2 = col_op(Dt, h, w, lr, gq), p2 = col_op(Pt, h, w, lr, gq);
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) {
-                dk[ct] = mfma32(col_op(Qt, h, ct), d2, dk[ct]);                  // dK[key][c] += sum_q dS[q][key] Q[q][c]
-                dv[ct] = mfma32(col_op(Gt, h, ct), p2, dv[ct]);                  // dV[key][c] += sum_q P[q][key] dO[q][c]
+                dk[ct] = mfma32(col_op(Qt, h, ct, lr, gq), d2, dk[ct]);                  // dK[key][c] += sum_q dS[q][key] Q[q][c]
+                dv[ct] = mfma32(col_op(Gt, h, ct, lr, gq), p2, dv[ct]);                  // dV[key][c] += sum_q P[q][key] dO[q][c]
             }
         }
         if (real) {
@@ -234,6 +297,16 @@ __global__ __launch_bounds__(256, 3) void blk_bwd_b16_k(const bf16_t* __restrict
 }
 
 }  // namespace
+
+int hwgat_launch_blk_fwd_b16(const void* qkv, void* o, const uint32_t* maskbits, int B, int F, int KJ, int nH, int shifted,
+                             hipStream_t st) {
+    BlkGeom g{F, KJ, nH, F / 2, nH * HD, shifted ? 1 : 0};
+    const int64_t units = (int64_t)B * g.f * nH;
+    const int64_t clip_bytes = (int64_t)F * KJ * 3 * g.d * 2;
+    if (units > 0x7fffffff || clip_bytes > 0x7fffffff) return HWGAT_ESHAPE;
+    blk_fwd_b16_k<<<(int)units, 256, 0, st>>>((const bf16_t*)qkv, (bf16_t*)o, maskbits, g, clip_bytes * B);
+    HWGAT_LAUNCH_CHECK();
+}
 
 int hwgat_launch_blk_bwd_b16(const void* qkv, const void* dO, void* dqkv, const uint32_t* maskbits, int B, int F, int KJ,
                              int nH, int shifted, hipStream_t st) {
