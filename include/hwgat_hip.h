@@ -293,6 +293,16 @@ int64_t hwgat_linear_tn_bf16_ws_bytes(int64_t M, int N, int K);
 int hwgat_linear_tn_bf16_ws(const void* A, const void* B, float* dW, float* db, int64_t M, int N, int K,
                             float* ws, int64_t ws_bytes, void* stream);
 
+/* hwgat_linear_tn_f32 with a caller-owned workspace of hwgat_linear_tn_f32_ws_bytes(M, N, K) bytes: where the 256x256-tile
+ * kernel takes the shape (N, K multiples of 256, more than one tile) the partial dW tiles of the M slices go to slabs and a
+ * second launch adds them in a FIXED order instead of 64 MB of global float atomics (~25 us less per launch, dW
+ * bit-reproducible).  Every argument as in hwgat_linear_tn_f32; ws == NULL, too small, or the query returned 0: identical
+ * to hwgat_linear_tn_f32. */
+int64_t hwgat_linear_tn_f32_ws_bytes(int64_t M, int N, int K);
+int hwgat_linear_tn_f32_ws(const float* A, const float* B, float* dW, float* db, int64_t M, int N, int K,
+                           uint32_t pro_seed, float pro_p, const float* mean, const float* rstd,
+                           const float* gamma, const float* beta, float* ws, int64_t ws_bytes, void* stream);
+
 /* out[C,R] = in[R,C]^T (used on weights only) */
 int hwgat_transpose_f32(const float* in, float* out, int R, int C, void* stream);
 

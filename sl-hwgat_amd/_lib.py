@@ -54,6 +54,8 @@ _SIGS = {
     "hwgat_linear_tn_f32": [_P, _P, _P, _P, _L, _I, _I, _U, _F, _P, _P, _P, _P, _P],
     "hwgat_linear_nt_bf16": [_P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _P, _U, _F, _I, _P, _P, _P, _U, _F, _P],
     "hwgat_linear_tn_bf16": [_P, _P, _P, _P, _L, _I, _I, _U, _F, _P, _P, _P, _P, _P],
+    "hwgat_linear_tn_f32_ws_bytes": [_L, _I, _I],
+    "hwgat_linear_tn_f32_ws": [_P, _P, _P, _P, _L, _I, _I, _U, _F, _P, _P, _P, _P, _P, _L, _P],
     "hwgat_linear_tn_bf16_ws_bytes": [_L, _I, _I],
     "hwgat_linear_tn_bf16_ws": [_P, _P, _P, _P, _L, _I, _I, _P, _L, _P],
     "hwgat_transpose_f32": [_P, _P, _I, _I, _P],

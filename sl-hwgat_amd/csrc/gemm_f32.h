@@ -55,7 +55,9 @@ struct TnArgs {
 
 // 256x256 dW tile, 4 waves x (128x128), one wave per SIMD, pinned MFMA/memory interleave (gemm_f32_tn256.hip);
 // needs N % 256 == K % 256 == 0; fills in n_split / rows_per_split itself
-int hwgat_launch_tn256(TnArgs a, hipStream_t st);
+// ws / ws_floats: optional workspace for the slab form (partial tiles + fixed-order reduction instead of global atomics)
+int hwgat_launch_tn256(TnArgs a, hipStream_t st, float* ws = nullptr, int64_t ws_floats = 0);
+int64_t hwgat_tn256_ws_floats(int64_t M, int N, int K);
 
 // 256x256 C tile, 4 waves x (128x128), one wave per SIMD, pinned MFMA/memory interleave (gemm_f32_nt256.hip);
 // needs M % 256 == N % 256 == K % 32 == 0; same prologues / epilogues as gemm_nt_k

@@ -690,6 +690,30 @@ extern "C" int hwgat_linear_nt_f32(const float* A, const float* W, const float* 
                                   epi_seed, epi_p, nullptr, nullptr, 0, 0, stream);
 }
 
+static bool tn256_takes(int64_t M, int N, int K, float pro_p, const float* mean) {
+    const int ov = tile_override();
+    return M % 32 == 0 && (ov == 0 || ov == 7) && N % 256 == 0 && K % 256 == 0 && (int64_t)N * K > 256 * 256 && !(pro_p > 0.f && mean);
+}
+
+extern "C" int64_t hwgat_linear_tn_f32_ws_bytes(int64_t M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0 || !tn256_takes(M, N, K, 0.f, nullptr)) return 0;
+    return hwgat_tn256_ws_floats(M, N, K) * 4;
+}
+
+extern "C" int hwgat_linear_tn_f32_ws(const float* A, const float* B, float* dW, float* db, int64_t M, int N,
+                                      int K, uint32_t pro_seed, float pro_p, const float* mean,
+                                      const float* rstd, const float* gamma, const float* beta, float* ws,
+                                      int64_t ws_bytes, void* stream) {
+    if (!A || !B || !dW || M <= 0 || N <= 0 || K <= 0) return HWGAT_EINVAL;
+    if (mean && (!rstd || !gamma || !beta)) return HWGAT_EINVAL;
+    if (pro_p < 0.f || pro_p >= 1.f) return HWGAT_EINVAL;
+    if (ws && ws_bytes > 0 && N % 128 == 0 && K % 128 == 0 && tn256_takes(M, N, K, pro_p, mean)) {
+        TnArgs a{A, B, dW, db, mean, rstd, gamma, beta, M, N, K, 0, 0, pro_seed, pro_p, 0};
+        return hwgat_launch_tn256(a, (hipStream_t)stream, ws, ws_bytes / 4);
+    }
+    return hwgat_linear_tn_f32(A, B, dW, db, M, N, K, pro_seed, pro_p, mean, rstd, gamma, beta, stream);
+}
+
 extern "C" int hwgat_linear_tn_f32(const float* A, const float* B, float* dW, float* db, int64_t M, int N,
                                    int K, uint32_t pro_seed, float pro_p, const float* mean,
                                    const float* rstd, const float* gamma, const float* beta, void* stream) {

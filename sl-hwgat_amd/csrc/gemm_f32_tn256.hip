@@ -37,8 +37,12 @@ __device__ __forceinline__ void il8() {
     }
 }
 
-template <int PRO, bool BLN>
-__global__ __launch_bounds__(256, 1) void gemm_tn256_k(TnArgs p) {
+// SLAB: the block's 256x256 partial tile goes to a workspace slab (lane-linear: every store instruction is 1 KB contiguous)
+// instead of 64 MB of memory-side float atomics per launch (~49 us at the ~1.3 TB/s they sustain); tn256_reduce_k then adds
+// the slabs of a tile in split order, so these weight gradients are also bit-reproducible (gemm_bf16_tn8w.hip did this first).
+//   ws[(split * n_tiles + tile) * 65536 + (((wave * 16 + i * 4 + jj) * 4 + q) * 64 + lane) * 4 + e] = acc[i][jj][4 q + e]
+template <int PRO, bool BLN, bool SLAB = false>
+__global__ __launch_bounds__(256, 1) void gemm_tn256_k(TnArgs p, float* __restrict__ ws = nullptr) {
     __shared__ __attribute__((aligned(16))) float sm[NST * STG];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane & 31, hh = lane >> 5;
@@ -169,16 +173,29 @@ __global__ __launch_bounds__(256, 1) void gemm_tn256_k(TnArgs p) {
     }
 
     // D[i = n][j = k]: lane (k = lq, hh), reg r -> dW[n = crow(r,hh)][k]
+    if constexpr (SLAB) {
+        float* slab = ws + ((int64_t)split * n_tiles + tile) * 65536 + wave * 16384 + lane * 4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
+            for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int n = n0 + wn * 128 + i * 32 + crow(r, hh);
-                const int k = k0 + wk * 128 + jj * 32 + lq;
-                atomicAdd(p.dW + (int64_t)n * p.K + k, acc[i][jj][r]);
-            }
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = {acc[i][jj][4 * q], acc[i][jj][4 * q + 1], acc[i][jj][4 * q + 2], acc[i][jj][4 * q + 3]};
+                    *reinterpret_cast<f32x4*>(slab + ((i * 4 + jj) * 4 + q) * 256) = v;
+                }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = n0 + wn * 128 + i * 32 + crow(r, hh);
+                    const int k = k0 + wk * 128 + jj * 32 + lq;
+                    atomicAdd(p.dW + (int64_t)n * p.K + k, acc[i][jj][r]);
+                }
+    }
     if (p.db != nullptr && k0 == 0) {
         float* red = sm;                                        // [4][256] partial column sums
         __syncthreads();
@@ -188,34 +205,79 @@ __global__ __launch_bounds__(256, 1) void gemm_tn256_k(TnArgs p) {
     }
 }
 
+// dW tile += the slabs of its M splits, in split order; one thread per slab float (256 workgroups per tile)
+__global__ __launch_bounds__(256) void tn256_reduce_k(const float* __restrict__ ws, float* __restrict__ dW, int n_split,
+                                                      int n_tiles, int tiles_k, int K) {
+    const int tile = blockIdx.x >> 8;
+    const int idx = (blockIdx.x & 255) * 256 + threadIdx.x;
+    const float* src = ws + (int64_t)tile * 65536 + idx;
+    const int64_t step = (int64_t)n_tiles * 65536;
+    float s = 0.f;
+    int sp = 0;
+    for (; sp + 8 <= n_split; sp += 8) {                       // eight loads in flight, added in split order
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = src[(sp + j) * step];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += v[j];
+    }
+    for (; sp < n_split; ++sp) s += src[sp * step];
+    const int e = idx & 3, lane = (idx >> 2) & 63, q = (idx >> 8) & 3, t = (idx >> 10) & 15, wave = idx >> 14;
+    const int i = t >> 2, jj = t & 3, lq = lane & 31, hh = lane >> 5, wn = wave >> 1, wk = wave & 1;
+    const int n0 = (tile / tiles_k) * BT, k0 = (tile % tiles_k) * BT;
+    dW[(int64_t)(n0 + wn * 128 + i * 32 + crow(4 * q + e, hh)) * K + k0 + wk * 128 + jj * 32 + lq] += s;
+}
+
 }  // namespace
 
-int hwgat_launch_tn256(TnArgs a, hipStream_t st) {
-    if (a.N % BT || a.K % BT || a.M % (2 * TM)) return HWGAT_ESHAPE;     // an even number of 16-row stages per M slice
-    const int n_tiles = (a.N / BT) * (a.K / BT);
-    // equal-sized blocks, one resident per CU (256 slots): blocks = n_split * n_tiles an exact multiple of 256
+// the M split of a launch: equal-sized blocks, one resident per CU (256 slots)
+static void tn256_split(int64_t M, int n_tiles, int& n_split, int64_t& rows_per_split) {
+    // blocks = n_split * n_tiles an exact multiple of 256
     auto gcd = [](int x, int y) { while (y) { int t = x % y; x = y; y = t; } return x; };
     const int r_min = n_tiles / gcd(n_tiles, 256);
     // The smallest whole number of rounds that fills every slot with equal blocks -- ONE round when the tile count
-    // divides 256.  Every M slice ends in n_tiles x 256 KB of float atomics (memory-side, ~1.3 TB/s chip-wide); the
-    // round-1 rule (at least two rounds) doubled that traffic for nothing: stage 2 dWproj 112.5 -> 118.6, dW1 124.3 ->
-    // 128.0, dW2 120.0 -> 123.2 TFLOP/s on one box; four rounds 104-119.  The split count has to stay a multiple of 8:
-    // split s lives on XCD s % 8 (its tiles share the M slice through that XCD's L2), and 21 splits x 12 tiles put
-    // 36 blocks on five of the XCDs' 32 CUs -- twice the time (measured).
+    // divides 256.  Every M slice ends in n_tiles x 256 KB of partial sums; the round-1 rule (at least two rounds) doubled
+    // that traffic for nothing: stage 2 dWproj 112.5 -> 118.6, dW1 124.3 -> 128.0, dW2 120.0 -> 123.2 TFLOP/s on one box;
+    // four rounds 104-119.  The split count has to stay a multiple of 8: split s lives on XCD s % 8 (its tiles share the
+    // M slice through that XCD's L2), and 21 splits x 12 tiles put 36 blocks on five of the XCDs' 32 CUs -- twice the
+    // time (measured).
     static const int min_rounds = [] { const char* e = lab_env("HWGAT_TN_ROUNDS"); return e ? atoi(e) : 1; }();
     int r = r_min;
     while (r < min_rounds) r += r_min;
     int64_t want = (int64_t)256 * r / n_tiles;
-    const int64_t max_split = a.M / (TM * 16) > 0 ? a.M / (TM * 16) : 1;
+    const int64_t max_split = M / (TM * 16) > 0 ? M / (TM * 16) : 1;
     if (want > max_split) want = max_split;
     if (want < 1) want = 1;
-    int64_t rows = (a.M + want - 1) / want;
+    int64_t rows = (M + want - 1) / want;
     rows = (rows + 2 * TM - 1) / (2 * TM) * (2 * TM);
-    a.n_split = (int)((a.M + rows - 1) / rows);
-    a.rows_per_split = rows;
+    n_split = (int)((M + rows - 1) / rows);
+    rows_per_split = rows;
+}
+
+// floats of workspace hwgat_launch_tn256 wants for the slab form of this shape (0: the shape does not take the kernel)
+int64_t hwgat_tn256_ws_floats(int64_t M, int N, int K) {
+    if (N % BT || K % BT || M % (2 * TM)) return 0;
+    const int n_tiles = (N / BT) * (K / BT);
+    int n_split;
+    int64_t rows;
+    tn256_split(M, n_tiles, n_split, rows);
+    return (int64_t)n_split * n_tiles * 65536;
+}
+
+int hwgat_launch_tn256(TnArgs a, hipStream_t st, float* ws, int64_t ws_floats) {
+    if (a.N % BT || a.K % BT || a.M % (2 * TM)) return HWGAT_ESHAPE;     // an even number of 16-row stages per M slice
+    const int n_tiles = (a.N / BT) * (a.K / BT);
+    tn256_split(a.M, n_tiles, a.n_split, a.rows_per_split);
     const int grid = ((a.n_split + 7) / 8) * 8 * n_tiles;
     const bool drop = a.pro_p > 0.f, ln = a.mean != nullptr;
     if (drop && ln) return HWGAT_ESHAPE;                         // not used by the model
+    if (ws && ws_floats >= (int64_t)a.n_split * n_tiles * 65536) {
+        if (drop) gemm_tn256_k<PRO_DROP, false, true><<<grid, 256, 0, st>>>(a, ws);
+        else if (ln) gemm_tn256_k<PRO_NONE, true, true><<<grid, 256, 0, st>>>(a, ws);
+        else gemm_tn256_k<PRO_NONE, false, true><<<grid, 256, 0, st>>>(a, ws);
+        tn256_reduce_k<<<n_tiles * 256, 256, 0, st>>>(ws, a.dW, a.n_split, n_tiles, a.K / BT, a.K);
+        HWGAT_LAUNCH_CHECK();
+    }
     if (drop) gemm_tn256_k<PRO_DROP, false><<<grid, 256, 0, st>>>(a);
     else if (ln) gemm_tn256_k<PRO_NONE, true><<<grid, 256, 0, st>>>(a);
     else gemm_tn256_k<PRO_NONE, false><<<grid, 256, 0, st>>>(a);

@@ -600,6 +600,14 @@ def linear_tn(A, Bm, dW, db=None, *, pro_seed=0, pro_p=0.0, ln=None):
             call("hwgat_linear_tn_bf16_ws", ptr(A), ptr(Bm), ptr(dW), ptr(db), M, N, K, ptr(ws), need, stream())
             return
     mean, rstd, gamma, beta = ln if ln is not None else (None, None, None, None)
+    if A.dtype == torch.float32:
+        # fp32, 256-aligned multi-tile outputs: slabs + fixed-order reduction as well (any prologue)
+        need = _lib.lib().hwgat_linear_tn_f32_ws_bytes(M, N, K)
+        if need > 0:
+            ws = torch.empty(need // 4, device=A.device, dtype=torch.float32)
+            call("hwgat_linear_tn_f32_ws", ptr(A), ptr(Bm), ptr(dW), ptr(db), M, N, K, pro_seed & 0xFFFFFFFF, float(pro_p),
+                 ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(ws), need, stream())
+            return
     call("hwgat_linear_tn_f32" if A.dtype == torch.float32 else "hwgat_linear_tn_bf16", ptr(A), ptr(Bm), ptr(dW), ptr(db), M, N, K, pro_seed & 0xFFFFFFFF,
          float(pro_p), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), stream())
 

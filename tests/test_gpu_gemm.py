@@ -96,6 +96,39 @@ def test_tn_weight_and_bias_grad(M, N, K, p):
     assert rel_err(dW.cpu(), 2 * ref) < TOL
 
 
+@pytest.mark.parametrize("M,N,K", [(8192, 512, 768), (32 * 129, 256, 512), (65536, 1536, 512)])
+@pytest.mark.parametrize("pro", ["plain", "drop", "ln"])
+def test_tn_f32_slab_reduction_every_tile_and_bit_reproducible(M, N, K, pro):
+    """fp32 weight gradients of 256-aligned multi-tile outputs (hwgat_linear_tn_f32_ws: partial tiles through workspace
+    slabs, added in split order by a second launch -- no global atomics): against fp64 tile by tile, for all three
+    prologues, accumulating into existing contents, and the same bits on every run"""
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    dY = torch.randn(M, N, device=DEV, generator=g)
+    X = torch.randn(M, K, device=DEV, generator=g) + 0.3
+    dW0 = torch.randn(N, K, device=DEV, generator=g)
+    kw, A64, B64 = {}, dY.double(), X.double()
+    if pro == "drop":
+        kw = dict(pro_seed=9, pro_p=0.1)
+        A64 = A64 * HF.dropout_mask((M, N), 9, 0.1, DEV).double()
+    elif pro == "ln":
+        gamma, beta = torch.randn(K, device=DEV, generator=g), torch.randn(K, device=DEV, generator=g)
+        mean = X.mean(-1)                                        # (hwgat_ln_fwd only knows the model's widths)
+        rstd = (X.var(-1, unbiased=False) + 1e-5).rsqrt()
+        kw = dict(ln=(mean, rstd, gamma, beta))
+        B64 = torch.nn.functional.layer_norm(B64, (K,), gamma.double(), beta.double())
+    assert hw._lib.lib().hwgat_linear_tn_f32_ws_bytes(M, N, K) > 0
+    runs = []
+    for _ in range(2):
+        dW, db = dW0.clone(), torch.zeros(N, device=DEV)
+        HF.linear_tn(dY, X, dW, db, **kw)
+        runs.append(dW)
+    assert torch.equal(runs[0], runs[1])
+    upd = A64.t() @ B64
+    err = (runs[0].double() - dW0.double() - upd).view(N // 256, 256, K // 256, 256).norm(dim=(1, 3))
+    assert float((err / upd.view(N // 256, 256, K // 256, 256).norm(dim=(1, 3))).max()) < TOL
+    assert rel_err(db.cpu(), A64.sum(0).cpu()) < TOL
+
+
 @pytest.mark.parametrize("M", [1, 29, 127, 129, 928, 864, 128 * 5 + 17])
 def test_ragged_token_counts(M):
     """M % 128 != 0 (HGATE: M = B*F*29): the last row block clamps its loads and guards its stores.
