@@ -423,7 +423,6 @@ class WeightPrep:
     OP_COPY, OP_T, OP_FOLD = 0, 1, 2
 
     def __init__(self, blocks, dtype, with_transposes):
-        import ctypes
         import numpy as np
         self.dtype = dtype
         dev = blocks[0].attn.qkv.weight.device
