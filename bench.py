@@ -627,7 +627,7 @@ def main():
         # separate passes; profiles/r01_attn_pmc_traffic.json) -- only valid for the shape they were taken on
         try:
             fname = (("r03_sibling_attn_bf16_pmc_traffic.json" if args.dtype == "bf16" else "r01k_sibling_attn_pmc_traffic.json")
-                     if (hgate or wgate) else "r02_attn_pmc_traffic.json")
+                     if (hgate or wgate) else "r03_attn_pmc_traffic.json")
             with open(os.path.join(ROOT, "profiles", fname)) as fh:
                 pmc = json.load(fh)
             if args.dtype == "bf16":
