@@ -268,6 +268,35 @@ def test_weight_prep_matches_the_per_call_kernels_and_follows_the_parameters(dty
     check(wp2)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_eval_forward_captured_in_a_hip_graph_equals_eager(dtype):
+    """serve.GraphedEval: the eval forward recorded once by HIP stream capture (the C-ABI launches go to torch's current
+    stream) and replayed -- bit-equal to the eager forward for new inputs, follows in-place weight updates, refuses other
+    shapes and train mode"""
+    serve = __import__("importlib").import_module("sl-hwgat_amd.serve")
+    torch.manual_seed(5)
+    K = 32
+    hp = hw.HWGATEParams({"src_len": 16, "num_class": 7}, 2, DEV, num_kps=K)
+    model = hw.Model(*hp.get_model_params()).to(DEV)
+    model.set_activation_dtype(dtype)
+    with pytest.raises(ValueError):
+        serve.GraphedEval(model.train(), torch.rand(2, 16, K, 2, device=DEV))
+    model.eval()
+    fast = serve.GraphedEval(model, torch.rand(2, 16, K, 2, device=DEV))
+    for seed in (1, 2):
+        x = torch.rand(2, 16, K, 2, device=DEV, generator=torch.Generator(device=DEV).manual_seed(seed))
+        with torch.no_grad():
+            ref = model(x)
+        assert torch.equal(fast(x), ref)
+    with torch.no_grad():
+        model.head.weight.mul_(0.5)                                  # in place: the replay reads the new values
+        model.layers[0].blocks[0].ff.fc1.weight.add_(0.01)
+        ref = model(x)
+    assert torch.equal(fast(x), ref)
+    with pytest.raises(ValueError):
+        fast(torch.rand(3, 16, K, 2, device=DEV))
+
+
 def test_model_with_attention_dropout_trains_and_eval_ignores_it():
     """attn_drop_rate is a constructor hyper-parameter of the reference (HWGATE.py:273) that a user can turn on: a
     model built with it runs train steps whose loss differs from the attn_drop_rate = 0 model on the same weights and
