@@ -584,7 +584,9 @@ extern "C" int hwgat_linear_nt_bf16_ex(const void* A, const void* W, const float
     // L2 -> LDS stream of the 128x128 tile) over the 256-aligned rows; HWGAT_NT_KERNEL=old keeps the 128x128 kernel
     static const bool nt_old = [] { const char* e = lab_env("HWGAT_NT_KERNEL"); return e && e[0] == 'o'; }();
     static const int nt256_min_k = [] { const char* e = lab_env("HWGAT_NT256_MINK"); return e ? atoi(e) : 128; }();
-    if (!nt_old && N % 256 == 0 && K >= nt256_min_k && M >= 256) {
+    // (fewer than 128 such tiles: the 128 x 128 kernel spreads a serving-size launch over four times as many CUs)
+    if (!nt_old && N % 256 == 0 && K >= nt256_min_k && M >= 256 &&
+        ((M / 256) * (N / 256) >= 128 || a.stat_sum != nullptr)) {     // (the row statistics of the 256-wide kernels are the order-fixed ones: eval determinism)
         const int64_t m256 = M / 256 * 256;
         NtArgsB b = a;
         b.M = m256;

@@ -649,7 +649,10 @@ extern "C" int hwgat_linear_nt_f32_ex(const float* A, const float* W, const floa
     // kernels, HWGAT_NT256_MINK moves the K threshold (A/B runs).
     static const bool nt_old = [] { const char* e = lab_env("HWGAT_NT_KERNEL"); return e && e[0] == 'o'; }();
     static const int nt256_min_k = [] { const char* e = lab_env("HWGAT_NT256_MINK"); return e ? atoi(e) : 128; }();
-    if (!nt_old && tile_override() == 0 && N % 256 == 0 && K >= nt256_min_k && M >= 256) {
+    // (serving batches: fewer than 128 tiles of 256 x 256 leave most of the 256 CUs without a tile -- the 128 x 128 kernel
+    //  has four times as many; B = 1 eval forward 3.96 -> see profiles/r03_serve_lab.txt)
+    if (!nt_old && tile_override() == 0 && N % 256 == 0 && K >= nt256_min_k && M >= 256 &&
+        ((M / 256) * (N / 256) >= 128 || a.stat_sum != nullptr)) {     // (the row statistics of the 256-wide kernels are the order-fixed ones: eval determinism)
         const int64_t m256 = M / 256 * 256;
         NtArgs b = a;
         b.M = m256;
