@@ -351,7 +351,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* tile, int m_base, int c0
 }
 
 template <int PRO, bool BLN, bool RAGGED = false>
-__global__ __launch_bounds__(256, 2) void gemm_tn_bf16_k(TnArgsB p) {
+__global__ __launch_bounds__(256, 3) void gemm_tn_bf16_k(TnArgsB p) {
     __shared__ __attribute__((aligned(16))) bf16_t sm[2 * 2 * TMB * LDW];    // [buf][A|B][32][160]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane & 31, hh = lane >> 5;
@@ -685,10 +685,15 @@ extern "C" int hwgat_linear_tn_bf16(const void* A, const void* B, float* dW, flo
     }
     const int n_tiles = (N / 128) * (K / 128);
     auto gcd = [](int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; };
-    const int r_min = n_tiles / gcd(n_tiles, 512);
+    // three 128x128 blocks per CU (40 KB of LDS, <= 168 registers), ONE round: every block ends in 64 KB of float atomics, so
+    // fewer, longer M slices are cheaper (tools/tnb_sweep.sh, stage 0 of config 3 per step: 512 blocks x 2 rounds 1.20 ms,
+    // 512 x 1 1.13, 768 x 1 1.09, 768 x 2 1.24, 1024 x 1 1.26)
+    static const int slots = [] { const char* e = lab_env("HWGAT_TNB_SLOTS"); return e ? atoi(e) : 768; }();      // blocks of one round
+    static const int min_rounds = [] { const char* e = lab_env("HWGAT_TNB_ROUNDS"); return e ? atoi(e) : 1; }();
+    const int r_min = n_tiles / gcd(n_tiles, slots);
     int r = r_min;
-    while (r < 2) r += r_min;
-    int64_t want = (int64_t)512 * r / n_tiles;
+    while (r < min_rounds) r += r_min;
+    int64_t want = (int64_t)slots * r / n_tiles;
     const int64_t max_split = M / (TMB * 16) > 0 ? M / (TMB * 16) : 1;
     if (want > max_split) want = max_split;
     if (want < 1) want = 1;

@@ -6,6 +6,15 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 hw = importlib.import_module("sl-hwgat_amd")
 HF = hw.functional
+if os.environ.get("TN_LAB_LIB") == "lab":                    # the LAB library (build.py --lab): its environment switches are live
+    import ctypes
+    L = hw._lib
+    L.lib()
+    lab = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sl-hwgat_amd", "libhwgat_hip_lab.so"))
+    for name, args in L._SIGS.items():
+        fn = getattr(lab, name)
+        fn.argtypes, fn.restype = args, (ctypes.c_int64 if name.endswith("_ws_bytes") else ctypes.c_int)
+    L._lib = lab
 dev = "cuda:0"
 B, T, K = 64, 128, 80
 dt = torch.bfloat16 if os.environ.get("NT_LAB_DTYPE", "f32") == "bf16" else torch.float32
