@@ -275,6 +275,13 @@ def test_embed(C, d0, J, nW):
     assert (out.cpu().double() - ref64).abs().max() < 2e-4
     out_nope = HF.embed(x.to(DEV), None if idx is None else idx.to(DEV), bmat.to(DEV), None, K)
     assert (out_nope.cpu() - O.fourier_embed(xs, bmat)).abs().max() < 2e-4
+    # bf16 output: hardware sine / cosine of the angle in revolutions (embed.hip); the error is the output rounding
+    # (values up to 2: half an ulp = 3.9e-3 + the ~2e-5 of the argument)
+    out_b = HF.embed(x.to(DEV), None if idx is None else idx.to(DEV), bmat.to(DEV), pe.view(T, d0).to(DEV), K,
+                     out_dtype=torch.bfloat16)
+    err = (out_b.cpu().double() - ref64).abs()
+    assert err.max() < 4.2e-3 and err.mean() < 1.2e-3
+    assert torch.equal(out_b.cpu(), ref64.to(torch.bfloat16)) or (out_b.cpu() != ref64.to(torch.bfloat16)).double().mean() < 0.02
 
 
 def test_merge_roundtrip():
