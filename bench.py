@@ -121,20 +121,22 @@ def _cpu_cell_worker(idx, cpus, threads, barrier, queue, c, K, steps, go):
 
 
 class _SaturatedCell:
-    """The host-saturating cell of `cpu_baseline`: N independent oracle processes that together occupy every physical
-    core -- N = min(4, physical_cores / 16), physical_cores / N threads each (4 x 32 on a 128-core host; the GPU box
-    admits at most 6 processes next to an open GPU context, and a freshly started torch process counts as one, so N
-    stays at 4) -- each pinned to its own block of CPUs (consecutive ids: one group of CCDs / NUMA node per process).
-    `start()` launches the interpreters (they import torch and build the oracle, then sleep on an event, so the
-    single-process cells are not disturbed); `run()` releases them together and returns the aggregate clips/s = all clips
-    of the timed steps / (last end - first start).  One 16-thread process leaves a 128-core host ~8x under-used; this is
-    the CPU's best."""
+    """The multi-process cell of `cpu_baseline`: N independent oracle processes -- N = min(4, physical_cores / 16); the GPU
+    box admits at most 6 processes next to an open GPU context and a freshly started torch process counts as one, so N
+    stays at 4 -- each with `threads` intra-op threads (16: the winner of every thread sweep so far; round 3 ran 32 per
+    process, which the sweep itself shows to be several times slower than 16) and pinned to `threads` CPUs of its own
+    quarter of the host (blocks a quarter of the CPU ids apart: separate CCD groups / NUMA nodes).  `start()` launches
+    the interpreters (they import torch and build the oracle, then sleep on an event, so the single-process cells are
+    not disturbed); `run()` releases them together and returns the aggregate clips/s = all clips of the timed steps /
+    (last end - first start) with the per-process rates next to it (contention shows as per-process rates below the
+    single-process cell).  4 x 16 threads use half of a 128-core host: that is what the process limit leaves."""
 
-    def __init__(self, c, K, phys, usable, threads=None, steps=2, max_proc=4):
+    def __init__(self, c, K, phys, usable, threads=16, steps=2, max_proc=4):
         import multiprocessing as mp
         cores = min(phys, usable)
-        self.n_proc = min(max_proc, max(1, cores // (threads or 16)))
-        self.threads = threads or (cores // max(self.n_proc, 1))
+        self.n_proc = min(max_proc, max(1, cores // threads))
+        self.threads = threads
+        self.stride = cores // max(self.n_proc, 1)       # CPU ids between the blocks of two processes
         self.steps, self.procs = steps, []
         if self.n_proc < 2:
             return
@@ -142,7 +144,7 @@ class _SaturatedCell:
         self.barrier, self.queue, self.go = ctx.Barrier(self.n_proc), ctx.Queue(), ctx.Event()
         avail = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
         for i in range(self.n_proc):
-            cpus = set(avail[i * self.threads:(i + 1) * self.threads])
+            cpus = set(avail[i * self.stride:i * self.stride + self.threads])   # own CCD group / NUMA node, `threads` CPUs of it
             self.procs.append(ctx.Process(target=_cpu_cell_worker, daemon=True,
                                           args=(i, cpus, self.threads, self.barrier, self.queue, c, K, steps, self.go)))
 
@@ -179,10 +181,11 @@ class _SaturatedCell:
         span = max(g[2] for g in ok) - min(g[1] for g in ok)
         return {"clips_per_s": round(sum(g[3] for g in ok) / span * self.n_proc / len(ok), 3), "processes": self.n_proc,
                 "finished": len(ok), "threads_per_process": self.threads, "timed_steps": self.steps,
+                "per_process_clips_per_s": [round(g[3] / (g[2] - g[1]), 3) for g in sorted(ok)],
                 "seconds": round(time.perf_counter() - t_begin, 1)}
 
 
-def cpu_baseline_saturated(c, K, phys, usable, threads=None, steps=3, limit_s=40.0, max_proc=4):
+def cpu_baseline_saturated(c, K, phys, usable, threads=16, steps=3, limit_s=40.0, max_proc=4):
     return _SaturatedCell(c, K, phys, usable, threads, steps, max_proc).start().run(limit_s)
 
 
@@ -215,7 +218,6 @@ def cpu_baseline(hgate=False, budget_s=45.0):
     if hgate:
         variants = variants[:1]                      # the HGATE oracle models neither threshold nor dropout
     t_start = time.perf_counter()
-    sat_cell = None if hgate else _SaturatedCell(c, K, phys, usable).start()   # interpreters come up meanwhile, then sleep
     # thread count: SURVEY 8d says "all physical cores", but on a 128-core host the small per-window ATen ops run
     # SLOWER with 128 threads than with 16-32 (first box measured: 0.9 vs 5.5 clips/s).  The baseline must be the
     # CPU's best, so a short sweep on the cheapest cell picks the thread count; every trial is recorded.
@@ -237,6 +239,8 @@ def cpu_baseline(hgate=False, budget_s=45.0):
         if time.perf_counter() - t_start > budget_s / 4:
             break
     threads = max(sweep, key=sweep.get)
+    # the multi-process cell gets the sweep's winner per process; its interpreters come up during the cells below, then sleep
+    sat_cell = None if hgate else _SaturatedCell(c, K, phys, usable, threads=threads).start()
     single_budget = budget_s - (10.0 if not hgate else 0.0)     # the host-saturating cell runs last
     torch.set_num_threads(threads)
     cells = {}
@@ -275,8 +279,9 @@ def cpu_baseline(hgate=False, budget_s=45.0):
             "thread_sweep_clips_per_s": {str(k): v for k, v in sweep.items()},
             "sample": f"oracle (torch CPU restatement) fwd+bwd on clips of the same T={c['T']} K={K} C={c['C']} "
                       f"d0={c['d0']} shape: single process, B in (2, 8) x variants (eval, train drop 0, train drop 0.1 = the "
-                      f"reference default), median of up to 3 timed steps after 1 warm-up; and the host-saturating cell "
-                      f"(physical_cores/16 pinned processes x 16 threads, eval B=2, aggregate); value = fastest ({best})",
+                      f"reference default), median of up to 3 timed steps after 1 warm-up; and the multi-process cell "
+                      f"({sat_cell.n_proc if sat_cell else 0} pinned processes x {sat_cell.threads if sat_cell else 0} threads, "
+                      f"eval B=2, aggregate); value = fastest ({best})",
             "cells": cells, "host_saturated": saturated, "seconds": round(time.perf_counter() - t_start, 1)}
 
 
@@ -623,8 +628,8 @@ def main():
                               "unit": "GB/s", "frac": round(ach / HBM_PEAK, 4), "traffic": None, "traffic_source": None,
                               "launches": n, "avg_us": round(avg * 1e6, 1),
                               "bytes_per_launch": attn_bytes(E, itemsize, bwd)}
-        # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 correction + WRITE_SIZE,
-        # separate passes; profiles/r01_attn_pmc_traffic.json) -- only valid for the shape they were taken on
+        # HBM bytes per launch from stored rocprofv3 PMC passes (FETCH_SIZE x2 correction + WRITE_SIZE, separate passes;
+        # the file named in `traffic_source`) -- only valid for the shape they were taken on
         try:
             fname = (("r03_sibling_attn_bf16_pmc_traffic.json" if args.dtype == "bf16" else "r01k_sibling_attn_pmc_traffic.json")
                      if (hgate or wgate) else "r03_attn_pmc_traffic.json")
@@ -711,7 +716,10 @@ def main():
             # the headline's model / optimizer / saved activations go first; its numbers above are final
             del step, opt, model
             torch.cuda.empty_cache()
-            out["secondary"] = {"config3_bf16": secondary_config3(hw, train_mod, dev)}
+            try:
+                out["secondary"] = {"config3_bf16": secondary_config3(hw, train_mod, dev)}
+            except Exception as exc:                        # noqa: BLE001 -- the headline above is final and must be printed
+                out["secondary"] = {"config3_bf16": {"error": repr(exc)}}
         if world == 1 and not args.no_cpu_baseline and args.config != 5:
             # after the timed regions; the GPU is idle meanwhile
             out["cpu_baseline"] = cpu_baseline_wgate() if wgate else cpu_baseline(hgate=hgate)

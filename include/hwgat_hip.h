@@ -45,6 +45,9 @@ extern "C" {
  *   3000  round 3: see INTEGRATION.md section 3 */
 #define HWGAT_ABI_VERSION 3000
 int hwgat_abi_version(void);
+/* 1 for the kernel-lab build (`python sl-hwgat_amd/build.py --lab`, libhwgat_hip_lab.so: environment A/B switches compiled
+ * in), 0 for the product library (reads no environment variables).  The lab tools assert 1 on the library they load. */
+int hwgat_is_lab_build(void);
 
 /* ---- debug: dump the lane->element maps of v_mfma_f32_32x32x2_f32 so the
  * host can verify the operand layouts the kernels assume.  out: 64*16 floats

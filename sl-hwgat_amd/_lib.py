@@ -22,6 +22,7 @@ _P, _I, _L = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
 _U, _F = ctypes.c_uint32, ctypes.c_float
 _SIGS = {
     "hwgat_abi_version": [],
+    "hwgat_is_lab_build": [],
     "hwgat_debug_mfma32x32x2": [_P, _P, _P, _P],
     "hwgat_debug_mfma_peak": [_P, _I, _I, _I, _P],
     "hwgat_embed_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _U, _F, _P],

@@ -16,9 +16,9 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 #define HWGAT_WAVE 64
 
 // The product library reads NO environment variables and keeps no mutable global state.  The A/B switches of the
-// kernel lab (tools/*_lab.py: alternative tile kernels, split counts, ...) exist only in a `HWGAT_LAB=1 python
-// sl-hwgat_amd/build.py` build (-DHWGAT_LAB); in the shipped build lab_env() is a constant null pointer and every
-// branch behind it folds away.
+// kernel lab (tools/*_lab.py: alternative tile kernels, split counts, ...) exist only in a `python sl-hwgat_amd/build.py
+// --lab` build (-DHWGAT_LAB, a separate libhwgat_hip_lab.so); in the shipped build lab_env() is a constant null pointer
+// and every branch behind it folds away.  hwgat_is_lab_build() tells a tool which of the two it loaded.
 #ifdef HWGAT_LAB
 #include <stdlib.h>
 inline const char* lab_env(const char* name) { return getenv(name); }

@@ -182,3 +182,10 @@ extern "C" int hwgat_unmerge_masked(const void* in, void* out, void* out_masked,
 }
 
 extern "C" int hwgat_abi_version(void) { return HWGAT_ABI_VERSION; }
+extern "C" int hwgat_is_lab_build(void) {
+#ifdef HWGAT_LAB
+    return 1;
+#else
+    return 0;
+#endif
+}

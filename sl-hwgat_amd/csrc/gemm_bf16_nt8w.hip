@@ -4,7 +4,7 @@
 //
 // Why another kernel.  gemm_nt256_bf16_k (one wave per SIMD, operands HBM/L2 -> VGPR -> ds_write_b128 -> LDS) tops out
 // at ~890 TFLOP/s on the plain launches, and its fused launches pay every per-element vector instruction of loaders and
-// epilogues at the single-wave issue rate with the matrix pipe idle.  This one changes both:
+// epilogues at the single-wave issue rate with the matrix pipe idle (LABLOG.md section 8).  This one changes both:
 //   * operands go HBM/L2 -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`): no staging registers, no ds_write pass, the
 //     loads of the next five phases stay in flight across barriers behind COUNTED `s_waitcnt vmcnt(6)` (never 0 in the
 //     steady state), workgroup barriers are raw `s_barrier` (a __syncthreads() would drain the DMA queue);

@@ -250,8 +250,25 @@ __global__ __launch_bounds__(256) void dw_reduce_k(const float* __restrict__ ws,
 
 }  // namespace
 
+// the M split of a shape: one round of equal blocks, one per CU: the split count a multiple of 8 (split s lives on XCD s % 8,
+// the tiles of a slice share its rows through that XCD's L2) with splits x tiles <= 256; slices are whole 128-row iterations
+static void tn8w_split(int64_t M, int n_tiles, int64_t* rows_per_split, int* n_split) {
+    int want = 256 / n_tiles / 8 * 8;
+    if (want < 8) want = 8;
+    const int64_t its = M / (2 * BM);
+    if (want > its) want = (int)its;
+    const int64_t per = (its + want - 1) / want;
+    *rows_per_split = per * (2 * BM);
+    *n_split = (int)((its + per - 1) / per);
+}
+
+// shapes this kernel takes; everything else (incl. a slice too long for the 32-bit DMA offsets) goes to the older kernels
 bool hwgat_tn8w_bf16_takes(int64_t M, int N, int K, float pro_p, const float* mean) {
-    return N % BT == 0 && K % BT == 0 && M % (2 * BM) == 0 && M >= 2 * BM && pro_p == 0.f && mean == nullptr;
+    if (!(N % BT == 0 && K % BT == 0 && M % (2 * BM) == 0 && M >= 2 * BM && pro_p == 0.f && mean == nullptr)) return false;
+    int64_t rows;
+    int n_split;
+    tn8w_split(M, (N / BT) * (K / BT), &rows, &n_split);
+    return rows * (N > K ? N : K) * 2 <= 0x7fffffff;             // 32-bit DMA offsets within a slice
 }
 
 // floats of workspace the slab form needs for this shape (every block's 256x256 tile), 0 if the kernel does not take it
@@ -266,16 +283,9 @@ int64_t hwgat_tn8w_bf16_ws_floats(int64_t M, int N, int K) {
 int hwgat_launch_tn8w_bf16(TnArgsB a, hipStream_t st, float* ws) {
     if (!hwgat_tn8w_bf16_takes(a.M, a.N, a.K, a.pro_p, a.mean)) return HWGAT_ESHAPE;
     const int n_tiles = (a.N / BT) * (a.K / BT);
-    // one round of equal blocks, one per CU: the split count a multiple of 8 (split s lives on XCD s % 8, the tiles of a
-    // slice share its rows through that XCD's L2) with splits x tiles <= 256; slices are whole 128-row iterations
-    int want = 256 / n_tiles / 8 * 8;
-    if (want < 8) want = 8;
-    const int64_t its = a.M / (2 * BM);
-    if (want > its) want = (int)its;
-    const int64_t per = (its + want - 1) / want;
-    a.rows_per_split = per * (2 * BM);
-    a.n_split = (int)((its + per - 1) / per);
-    if ((int64_t)a.rows_per_split * (a.N > a.K ? a.N : a.K) * 2 > 0x7fffffff) return HWGAT_ESHAPE;   // 32-bit DMA offsets within a slice
+    int64_t rows;
+    tn8w_split(a.M, n_tiles, &rows, &a.n_split);
+    a.rows_per_split = rows;
     const int grid = ((a.n_split + 7) / 8) * 8 * n_tiles;
     if (ws) {
         gemm_tn8w_bf16_k<true><<<grid, 512, 0, st>>>(a, ws);

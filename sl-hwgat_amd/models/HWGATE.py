@@ -154,6 +154,10 @@ class Model(nn.Module):
                 + getattr(self, "rank_salt", 0) * 0x27D4EB2F) & 0xFFFFFFFF
         return [(base + (k * 4 + s) * 0xC2B2AE35) & 0xFFFFFFFF for s in range(4)]
 
+    def block_list(self):
+        """every PartAttentionBlock container in execution order (what functional.weight_prep derives the copies of)"""
+        return [blk for st in self.layers for blk in st.blocks]
+
     def _block(self, h, blk, n_heads, shifted, thr, k, hand):
         """one PartAttentionBlock (HWGATE.py:189-221) = one fused autograd node (block.fused_block).  `hand` is the
         HandOver of THIS forward call: what the previous block's epilogues produced for this one (LayerNorm statistics of
@@ -196,8 +200,7 @@ class Model(nn.Module):
         n_blocks = sum(len(st.blocks) for st in self.layers)
         hand = HF.HandOver(last_block=n_blocks - 1, deterministic=self.deterministic_eval and not self.training)
         # every derived copy of the block weights this call needs (LayerNorm folds, bf16 copies, transposes for the backward)
-        hand.prep = HF.weight_prep(self, [blk for st in self.layers for blk in st.blocks], self.activation_dtype,
-                                   torch.is_grad_enabled())
+        hand.prep = HF.weight_prep(self, self.block_list(), self.activation_dtype, torch.is_grad_enabled())
         kk = 0
         for i, stage in enumerate(self.layers):          # every block but the last feeds a LayerNorm; stage ends merge
             for j in range(len(stage.blocks)):

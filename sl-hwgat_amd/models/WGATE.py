@@ -86,10 +86,13 @@ class Model(_base.Model):
         if device is not None:
             self.to(device)
 
+    def block_list(self):
+        return list(self.layers)
+
     def forward_features(self, x):
         h = self._embed(x)
         hand = HF.HandOver(last_block=self.depths - 1, deterministic=self.deterministic_eval and not self.training)
-        hand.prep = HF.weight_prep(self, list(self.layers), self.activation_dtype, torch.is_grad_enabled())
+        hand.prep = HF.weight_prep(self, self.block_list(), self.activation_dtype, torch.is_grad_enabled())
         for k in range(self.depths):                   # every block but the last feeds the next block's LayerNorm
             hand.plan[k] = (k < self.depths - 1, False)
         for k, blk in enumerate(self.layers):          # PartAttentionBlock.forward, WGATE.py:150-160

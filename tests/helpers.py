@@ -49,6 +49,43 @@ def rel_err(a, b):
     return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
 
 
+def tie_free_threshold(p0, nominal, span=1.25):
+    """A train-mode threshold (reference HWGATE.py:94-100) near `nominal` that no entry of the unmasked softmax `p0`
+    (the fp64 oracle's, any shape) comes close to: the geometric centre of the widest relative gap between neighbouring
+    values inside [nominal / span, nominal * span].  Returns (thr, margin) with margin = the relative distance from thr
+    to the nearest probability.  With it the selector [p0 <= thr] cannot flip under rounding smaller than `margin`, so a
+    kernel can be held to its arithmetic tolerance in train mode too."""
+    lo, hi = nominal / span, nominal * span
+    v = torch.as_tensor(p0, dtype=torch.float64).flatten()
+    v = v[(v > lo) & (v < hi)].sort().values
+    edges = torch.cat([torch.tensor([lo], dtype=torch.float64), v, torch.tensor([hi], dtype=torch.float64)])
+    ratio = edges[1:] / edges[:-1]
+    i = int(ratio.argmax())
+    return float((edges[i] * edges[i + 1]).sqrt()), float(ratio[i].sqrt() - 1.0)
+
+
+BF16_SELECTOR_BAND = 2.0 ** -6
+
+
+def oracle_threshold_bracket(run, thresholds, band=BF16_SELECTOR_BAND):
+    """Train-mode parity of a WHOLE bf16 model has a discontinuity no threshold can dodge: the selector [P0 <= thr] of
+    reference HWGATE.py:94-100 is evaluated on scores formed from bf16 activations (relative error ~2^-8 per layer), so
+    a probability within about `band` (relative) of the threshold may fall on either side, and with 10^5..10^7
+    probabilities per block some always are that close.  Instead of waiving the assertions, the test BRACKETS the flips:
+    `run(thresholds)` -> (logits, {name: grad}) is evaluated by the fp64 oracle at thr, thr * (1 + band) (every entry
+    of the band kept) and thr * (1 - band) (every entry of the band dropped).  An implementation whose selector differs
+    from the oracle's only inside the band must land within its arithmetic tolerance + the distance the band itself can
+    move the result.  Returns (ref_out, ref_grads, width_out, {name: width}) with width = relative L2 distance between
+    the two bracket ends; the caller adds 2 x width to its tolerance and asserts that width is small (else the test
+    would have no teeth)."""
+    ref_out, ref_g = run(list(thresholds))
+    hi_out, hi_g = run([t * (1.0 + band) for t in thresholds])
+    lo_out, lo_g = run([t * (1.0 - band) for t in thresholds])
+    w_out = rel_err(hi_out, lo_out)
+    w_g = {k: rel_err(hi_g[k], lo_g[k]) for k in ref_g}
+    return ref_out, ref_g, w_out, w_g
+
+
 def probe_vectors(name, n, k=4):
     """the k fixed +-1 vectors tests/golden/make_fixtures.py::probe_vectors projects a gradient on"""
     import zlib

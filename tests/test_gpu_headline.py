@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from oracle import hwgat_oracle as O
-from helpers import load_fixture, cfg_of, rel_err, grad_digest_check, natural
+from helpers import load_fixture, cfg_of, rel_err, grad_digest_check, natural, oracle_threshold_bracket
 
 pytestmark = pytest.mark.gpu
 hw = importlib.import_module("sl-hwgat_amd")
@@ -176,6 +176,43 @@ def test_batch_8_bf16_all_gradients_entrywise_against_the_oracle():
     assert len(errs) == sum(1 for k in ref_p if ref_p[k].requires_grad)
     for name, e in errs.items():
         assert e < BF16_GRAD_TOL, (name, e)
+
+
+def test_batch_4_bf16_train_mode_all_gradients_within_the_threshold_bracket():
+    """The same entry-by-entry gradient check in TRAIN mode (thresholds injected, dropout off; HWGATE.py:94-100) for the
+    bf16 arithmetic of BASELINE configs[2].  A probability within bf16 rounding of a threshold may be selected either
+    way, so the fp64 oracle is run at thr and at thr * (1 +- 2^-6): every parameter gradient must be within the bf16
+    bound + twice the distance between the bracket ends, and that distance must itself be small (measured, printed)."""
+    fx = load_fixture("cfg2_clip.npz")
+    model, cfg, params = build(fx, torch.bfloat16)
+    g = torch.Generator().manual_seed(77)
+    x = torch.rand(4, *fx["x"].shape[1:], generator=g)
+    y = torch.randint(0, cfg["num_classes"], (4,), generator=g)
+    thr = [0.3, 0.1, 0.5, 0.2, 0.07, 0.4, 0.25, 0.6]
+
+    def run_oracle(t):
+        ref_p = {k: v.double().requires_grad_(k not in ("B", "pos_encoder.pe")) for k, v in params.items()}
+        oracle = O.OracleHWGAT(ref_p, num_kps=cfg["num_kps"], temporal_dim=cfg["temporal_dim"])
+        ref = oracle.forward(x.double(), thresholds=t)
+        O.smoothed_cross_entropy(ref, y).backward()
+        return ref.detach(), {k: v.grad for k, v in ref_p.items() if v.requires_grad}
+
+    ref, ref_g, w_out, w_g = oracle_threshold_bracket(run_oracle, thr)
+    eval_out, _ = run_oracle(None)
+    assert rel_err(eval_out, ref) > 2 * (BF16_TOL + 2 * w_out)  # the thresholds change the function: the check has teeth
+    model.train()
+    model.threshold_override = thr
+    out = model(x.to(DEV))
+    O.smoothed_cross_entropy(out.float(), y.to(DEV)).backward()
+    print("bracket width: logits", w_out, "worst gradient", max(w_g.values()))
+    assert w_out < 1e-2 and max(w_g.values()) < BF16_GRAD_TOL, (w_out, max(w_g, key=w_g.get), max(w_g.values()))
+    assert rel_err(out.float().detach().cpu(), ref) < BF16_TOL + 2 * w_out
+    errs = {name: rel_err(prm.grad.float().cpu(), ref_g[name]) for name, prm in model.named_parameters() if prm.grad is not None}
+    assert len(errs) == len(ref_g)
+    worst = max(errs, key=lambda k: errs[k] - 2 * w_g[k])
+    print("B=4 bf16 train-mode worst gradient rel err", worst, errs[worst], "bracket", w_g[worst])
+    for name, e in errs.items():
+        assert e < BF16_GRAD_TOL + 2 * w_g[name], (name, e, w_g[name])
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

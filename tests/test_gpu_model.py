@@ -8,7 +8,7 @@ import torch
 
 from oracle import hwgat_oracle as O
 from libgemm_path import use_library_linears
-from helpers import load_fixture, cfg_of, oracle_from_fixture, rel_err, grad_digest_check, sub, natural
+from helpers import load_fixture, cfg_of, oracle_from_fixture, rel_err, grad_digest_check, sub, natural, oracle_threshold_bracket
 
 pytestmark = pytest.mark.gpu
 hw = importlib.import_module("sl-hwgat_amd")
@@ -295,6 +295,13 @@ def test_eval_forward_captured_in_a_hip_graph_equals_eager(dtype):
     assert torch.equal(fast(x), ref)
     with pytest.raises(ValueError):
         fast(torch.rand(3, 16, K, 2, device=DEV))
+    # a REALLOCATED parameter (the graph holds the old address, the derived copies the old source): refused, not replayed
+    w = model.layers[0].blocks[0].attn.qkv.weight
+    w.data = w.data.clone()
+    with torch.no_grad():
+        model(x)                                                     # an eager forward rebuilds the model's WeightPrep cache
+    with pytest.raises(RuntimeError, match="capture again"):
+        fast(x)
 
 
 def test_model_with_attention_dropout_trains_and_eval_ignores_it():
@@ -555,22 +562,36 @@ def test_wide_config_fully_fused_vs_oracle(dtype):
     g = torch.Generator().manual_seed(8)
     x = torch.rand(B, T, nW * 16, C, generator=g)
     y = torch.randint(0, nc, (B,), generator=g)
-    for thr in (None, [0.3, 0.1, 0.5, 0.2, 0.07, 0.4, 0.25, 0.6]):
+    names = ("layers.2.blocks.3.ff.fc2.weight", "layers.1.blocks.1.attn.qkv.weight", "layers.0.blocks.0.norm1.weight", "head.weight")
+
+    def run_oracle(thr):
         ref_p = {k: v.double().requires_grad_(k not in ("B", "pos_encoder.pe")) for k, v in params.items()}
         oracle = O.OracleHWGAT(ref_p, num_kps=nW * 16, temporal_dim=T, adj=O.window_adjacency(nW))
         ref = oracle.forward(x.double(), thresholds=thr)
         O.smoothed_cross_entropy(ref, y).backward()
+        return ref.detach(), {k: ref_p[k].grad for k in names}
+
+    eval_ref = None
+    for thr in (None, [0.3, 0.1, 0.5, 0.2, 0.07, 0.4, 0.25, 0.6]):
+        w_out, w_g = 0.0, {k: 0.0 for k in names}
+        if thr is not None and dtype == torch.bfloat16:
+            # train mode under bf16: the selector of HWGATE.py:94-100 may flip for probabilities within 2^-6 of the
+            # threshold; the oracle brackets those flips and the assertions keep their teeth (helpers.oracle_threshold_bracket)
+            ref, ref_g, w_out, w_g = oracle_threshold_bracket(run_oracle, thr)
+            assert w_out < 1e-2 and max(w_g.values()) < 4e-2, (w_out, w_g)      # a narrow bracket, or the test says nothing
+        else:
+            ref, ref_g = run_oracle(thr)
+        if thr is None:
+            eval_ref = ref
+        else:
+            assert rel_err(eval_ref, ref) > 2 * (1e-2 + 2 * w_out)   # the thresholds matter: ignoring them is outside the bound below
         model.train(thr is not None)
         model.threshold_override = thr
         model.zero_grad()
         out = model(x.to(DEV))
         O.smoothed_cross_entropy(out.float(), y.to(DEV)).backward()
-        # bf16: the contract's 1e-2 in eval mode; in train mode a probability within bf16 rounding of the threshold
-        # flips the selector of HWGATE.py:94-100 (a discontinuity, not an arithmetic error), hence the looser bound
-        tol = 1e-3 if dtype == torch.float32 else (1e-2 if thr is None else 3e-2)
-        assert rel_err(out.float().detach().cpu(), ref.detach()) < tol, (dtype, thr is not None, "train-mode bf16 "
-                                                                        "bound is loose only for threshold ties")
-        if dtype == torch.float32 or thr is None:      # under bf16 the threshold selector may flip near ties
-            for name in ("layers.2.blocks.3.ff.fc2.weight", "layers.1.blocks.1.attn.qkv.weight", "layers.0.blocks.0.norm1.weight", "head.weight"):
-                got = dict(model.named_parameters())[name].grad.double().cpu()
-                assert rel_err(got, ref_p[name].grad) < (2e-3 if dtype == torch.float32 else 8e-2), name
+        tol = 1e-3 if dtype == torch.float32 else 1e-2 + 2 * w_out
+        assert rel_err(out.float().detach().cpu(), ref) < tol, (dtype, thr is not None, w_out)
+        for name in names:
+            got = dict(model.named_parameters())[name].grad.double().cpu()
+            assert rel_err(got, ref_g[name]) < (2e-3 if dtype == torch.float32 else 8e-2 + 2 * w_g[name]), (name, w_g[name])

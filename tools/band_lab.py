@@ -6,6 +6,7 @@ hw = importlib.import_module("sl-hwgat_amd")
 HF, L = hw.functional, hw._lib
 from oracle import wgat_oracle as OW
 lab = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sl-hwgat_amd", "libhwgat_hip_lab.so"))
+assert lab.hwgat_is_lab_build() == 1, "not the LAB library: build it with `python sl-hwgat_amd/build.py --lab`"
 for name, args in L._SIGS.items():
     fn = getattr(lab, name)
     fn.argtypes, fn.restype = args, ctypes.c_int

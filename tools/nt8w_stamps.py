@@ -9,6 +9,7 @@ sys.path.insert(0, ROOT)
 hw = importlib.import_module("sl-hwgat_amd")
 HF, L = hw.functional, hw._lib
 lab = ctypes.CDLL(os.path.join(ROOT, "sl-hwgat_amd", "libhwgat_hip_lab.so"))
+assert lab.hwgat_is_lab_build() == 1, "not the LAB library: build it with `python sl-hwgat_amd/build.py --lab`"
 for name, args in L._SIGS.items():
     fn = getattr(lab, name)
     fn.argtypes, fn.restype = args, ctypes.c_int

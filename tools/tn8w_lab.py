@@ -13,6 +13,7 @@ HF, L = hw.functional, hw._lib
 dev = "cuda:0"
 new = L.lib()
 old = ctypes.CDLL(os.path.join(ROOT, "sl-hwgat_amd", "libhwgat_hip_lab.so"))
+assert old.hwgat_is_lab_build() == 1, "not the LAB library: build it with `python sl-hwgat_amd/build.py --lab`"
 for name, args in L._SIGS.items():
     fn = getattr(old, name)
     fn.argtypes, fn.restype = args, ctypes.c_int

@@ -11,6 +11,7 @@ if os.environ.get("TN_LAB_LIB") == "lab":                    # the LAB library (
     L = hw._lib
     L.lib()
     lab = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sl-hwgat_amd", "libhwgat_hip_lab.so"))
+    assert lab.hwgat_is_lab_build() == 1, "not the LAB library: build it with `python sl-hwgat_amd/build.py --lab`"
     for name, args in L._SIGS.items():
         fn = getattr(lab, name)
         fn.argtypes, fn.restype = args, (ctypes.c_int64 if name.endswith("_ws_bytes") else ctypes.c_int)
