@@ -308,12 +308,83 @@ def visible_gpu_count():
     return n
 
 
-def secondary_config3(hw, train_mod, dev, steps=10, warmup=6):
-    """BASELINE configs[2] (the headline shape with bf16 activations / bf16 MFMA linears, the HBM-bound variant) measured
-    in the SAME process right after the headline, so that every driver run of the default `python bench.py` also
-    records it: same full train step (zero_grad + fwd + loss + bwd + fused AdamW), train mode, inputs resident in HBM.
-    Returns the object stored under `secondary.config3_bf16`; the headline `value` is untouched by it."""
-    c = CFG
+def _cpulist(text):
+    """'0-15,128-143' -> [0..15, 128..143]"""
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out.extend(range(int(a), int(b or a) + 1))
+    return out
+
+
+def gpu_local_cpus(index, sysfs="/sys"):
+    """CPUs of the NUMA node that GPU `index` (HIP order) hangs off, from sysfs ONLY -- no HIP / torch.cuda call, so the
+    spawning parent and a rank that has not touched its GPU yet can both use it: KFD topology nodes with SIMDs are the
+    GPUs in HIP order (re-mapped through an integer *_VISIBLE_DEVICES list), a node's `domain` / `location_id`
+    ((bus << 8) | (device << 3) | function) give its PCI address, and /sys/bus/pci/devices/<address>/local_cpulist names
+    the CPUs next to it.  Returns (sorted CPU list, "domain:bus:dev.fn") or (None, reason)."""
+    import glob
+    gpus = []
+    for path in sorted(glob.glob(os.path.join(sysfs, "class/kfd/kfd/topology/nodes/*/properties")),
+                       key=lambda q: int(q.split(os.sep)[-2])):
+        try:
+            with open(path) as fh:
+                props = dict(ln.split(None, 1) for ln in fh.read().splitlines() if " " in ln)
+            if int(props.get("simd_count", "0")) > 0:
+                gpus.append((int(props.get("domain", "0")), int(props["location_id"])))
+        except (OSError, ValueError, KeyError):
+            return None, "unreadable KFD topology"
+    if not gpus:
+        return None, "no KFD topology in sysfs"
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            try:
+                gpus = [gpus[int(t)] for t in v.split(",") if t.strip()]
+            except (ValueError, IndexError):
+                return None, f"{var} is not an integer list"
+            break
+    if not 0 <= index < len(gpus):
+        return None, f"GPU {index} not in the topology ({len(gpus)} GPUs)"
+    dom, loc = gpus[index]
+    bdf = f"{dom:04x}:{(loc >> 8) & 0xff:02x}:{(loc >> 3) & 0x1f:02x}.{loc & 7}"
+    try:
+        with open(os.path.join(sysfs, "bus/pci/devices", bdf, "local_cpulist")) as fh:
+            cpus = _cpulist(fh.read())
+    except (OSError, ValueError):
+        return None, f"no local_cpulist for {bdf}"
+    return (sorted(cpus), bdf) if cpus else (None, f"empty local_cpulist for {bdf}")
+
+
+def pin_rank_to_gpu_cpus(local_rank, local_world, sysfs="/sys"):
+    """Pin this rank process to its share of the CPUs next to its GPU (with 8 Python ranks on one host the
+    step is ~400 launches per 20-100 ms; a rank whose launches are issued from the far socket, or that migrates between
+    cores, shows up as launch jitter).  The GPUs of this job that share a NUMA node split that node's CPU list evenly,
+    in rank order.  Returns a record for the JSON line; never fatal (an unreadable topology leaves the affinity alone)."""
+    if not hasattr(os, "sched_setaffinity"):
+        return {"pinned": False, "reason": "no sched_setaffinity"}
+    mine, where = gpu_local_cpus(local_rank, sysfs)
+    if mine is None:
+        return {"pinned": False, "reason": where}
+    peers = [r for r in range(local_world) if gpu_local_cpus(r, sysfs)[0] == mine]
+    slot = peers.index(local_rank)
+    per = len(mine) // len(peers)
+    share = set(mine[slot * per:(slot + 1) * per]) & set(os.sched_getaffinity(0))
+    if len(share) < 2:
+        return {"pinned": False, "reason": f"share of {where}'s CPUs outside this process's affinity mask", "pci": where}
+    os.sched_setaffinity(0, share)
+    return {"pinned": True, "pci": where, "cpus": len(share), "first_cpu": min(share), "last_cpu": max(share),
+            "ranks_sharing_node": len(peers)}
+
+
+def secondary_run(hw, train_mod, dev, c, label, steps, warmup, micro_batch=None):
+    """A second BASELINE config measured in the SAME process right after the headline, so that every driver run of the
+    default `python bench.py` also records it: BASELINE configs[2] (the headline shape with bf16 activations / bf16 MFMA
+    linears, the HBM-bound variant) and configs[4] (the stress shape, micro-batched) -- the same full train step
+    (zero_grad + fwd + loss + bwd + fused AdamW), train mode, inputs resident in HBM.  Returns the object stored under
+    `secondary.<name>`; the headline `value` is untouched by it."""
     K = c["nW"] * 16
     HF = hw.functional
     torch.manual_seed(1001)
@@ -323,7 +394,7 @@ def secondary_config3(hw, train_mod, dev, steps=10, warmup=6):
     model.set_activation_dtype(torch.bfloat16)
     model.train()
     opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=5e-4, fused=True)
-    step = train_mod.TrainStep(model, opt, None)
+    step = train_mod.TrainStep(model, opt, None, micro_batch=micro_batch)
     g = torch.Generator(device=dev).manual_seed(7)
     x = torch.rand(c["B"], c["T"], c["J"], c["C"], device=dev, generator=g)
     y = torch.randint(0, c["nc"], (c["B"],), device=dev, generator=g)
@@ -335,15 +406,18 @@ def secondary_config3(hw, train_mod, dev, steps=10, warmup=6):
         step(x, y)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    n_ev = 2 if micro_batch is None else 1
     HF.TIMERS = store = {}
-    for _ in range(2):                                   # two more steps with per-launch HIP events: kernel durations
+    for _ in range(n_ev):                                # more steps with per-launch HIP events: kernel durations
         step(x, y)
     timers = HF.timers_summary()
     HF.TIMERS = None
     del store
     rate = c["B"] * steps / elapsed
     e_clip = c["T"] * K * c["d0"]
-    E = c["B"] * e_clip
+    b_launch = min(micro_batch or c["B"], c["B"])
+    E = b_launch * e_clip
+    n_micro = -(-c["B"] // b_launch)
     bytes_clip = 364.0 * e_clip * 2                      # (45 E s per block) x 8 + 4 E s, s = 2
     flops_clip = 3.0 * (16.0 * sum(dep * c["d0"] * 2 ** i for i, dep in enumerate((2, 2, 4))) + 128.0 * 8) * e_clip
     kern = {}
@@ -358,18 +432,28 @@ def secondary_config3(hw, train_mod, dev, steps=10, warmup=6):
         n2, ms2 = timers.get(name + "_ex", (0, 0.0))
         n3, ms3 = timers.get(name + "_ws", (0, 0.0))
         if n + n2 + n3:
-            kern[name] = {"launches_per_step": (n + n2 + n3) // 2, "ms_per_step": round((ms + ms2 + ms3) / 2, 3)}
+            kern[name] = {"launches_per_step": (n + n2 + n3) // n_ev, "ms_per_step": round((ms + ms2 + ms3) / n_ev, 3)}
     return {"value": round(rate, 2), "unit": "clips/s", "dtype": "bf16", "steps": steps, "warmup": warmup,
             "ms_per_step": round(elapsed / steps * 1e3, 3),
-            "config": {"workload": f"BASELINE configs[2]: HWGAT train step (fwd+loss+bwd+AdamW), B={c['B']}/GPU T={c['T']} "
+            "config": {"workload": f"{label}: HWGAT train step (fwd+loss+bwd+AdamW), B={c['B']}/GPU T={c['T']} "
                                    f"J={c['J']}->K={K} C={c['C']} d_model={c['d0']} depths[2,2,4] classes={c['nc']}, bf16 "
-                                   f"activations + bf16 MFMA linears, train-mode drop 0.1"},
+                                   f"activations + bf16 MFMA linears, train-mode drop 0.1"
+                                   + (f", micro-batch {b_launch} ({n_micro} slices, gradient accumulation)" if micro_batch else "")},
             "roofline_end_to_end": {"bound": "hbm", "achieved": round(rate * bytes_clip / 1e9, 1), "peak": HBM_PEAK / 1e9,
                                     "unit": "GB/s", "frac": round(rate * bytes_clip / HBM_PEAK, 4), "bytes_per_clip": bytes_clip,
                                     "other_roof": {"bound": "mfma", "achieved": round(rate * flops_clip / 1e12, 1), "peak": 2500.0,
                                                    "unit": "TFLOP/s", "frac": round(rate * flops_clip / 2.5e15, 4)}},
-            "kernels": kern, "hip_kernel_ms_per_step": round(sum(v[1] for v in timers.values()) / 2, 3),
+            "kernels": kern, "hip_kernel_ms_per_step": round(sum(v[1] for v in timers.values()) / n_ev, 3),
             "loss": round(float(step.loss), 4)}
+
+
+def secondary_config3(hw, train_mod, dev, steps=10, warmup=6):
+    return secondary_run(hw, train_mod, dev, CFG, "BASELINE configs[2]", steps, warmup)
+
+
+def secondary_config5(hw, train_mod, dev, steps=2, warmup=1):
+    """BASELINE configs[4], the stress shape (B=256 T=256 J=133->K=112 C=3 d0=256), bf16, micro-batch 32: ~0.7 s per step"""
+    return secondary_run(hw, train_mod, dev, CFG5, "BASELINE configs[4] (stress)", steps, warmup, micro_batch=32)
 
 
 def spawn_ranks(n, argv):
@@ -431,22 +515,41 @@ def spawn_ranks(n, argv):
     sys.stdout.flush()
 
 
+def dist_record(dist, world, device_name, step_ms, pin):
+    """what the process group actually was, gathered from every rank (collective: all ranks call it): backend, the world
+    size torch.distributed reports, every rank's device, the spread of the per-rank step time, every rank's CPU pinning"""
+    mine = {"rank": dist.get_rank(), "device": device_name, "step_ms": round(step_ms, 3), "cpu_pin": pin,
+            "pid": os.getpid()}
+    every = [None] * world
+    dist.all_gather_object(every, mine)
+    every.sort(key=lambda r: r["rank"])
+    steps = [r["step_ms"] for r in every]
+    return {"backend": dist.get_backend(), "world_size_seen": dist.get_world_size(), "devices": [r["device"] for r in every],
+            "step_ms_min": min(steps), "step_ms_max": max(steps), "cpu_pin": [r["cpu_pin"] for r in every],
+            "distinct_processes": len({r["pid"] for r in every})}
+
+
 def dry_run(args, json_fd):
     """HWGAT_BENCH_DRYRUN=1: the launcher / rendezvous / max-over-ranks / one-JSON-line plumbing on the gloo
     backend with no model and no GPU (tests/test_dist_cpu.py); `value` is meaningless."""
     import torch.distributed as dist
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local, local_world = int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    pin = pin_rank_to_gpu_cpus(local, local_world, os.environ.get("HWGAT_BENCH_SYSFS", "/sys")) if world > 1 else None
     if world > 1:
         dist.init_process_group("gloo")
     if os.environ.get("HWGAT_BENCH_DRYRUN_FAIL_RANK") == str(rank):
         sys.exit(3)
-    t = torch.tensor([0.001 * (rank + 1)], dtype=torch.float64)
+    mine = 0.001 * (rank + 1)
+    t = torch.tensor([mine], dtype=torch.float64)
     if world > 1:
         dist.barrier()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    info = dist_record(dist, world, f"dry-run device of rank {rank}", mine * 1e3 / max(args.steps, 1), pin) if world > 1 else None
     if rank == 0:
         out = {"metric": "dry-run", "value": 0.0, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "max_elapsed": float(t), "config": {"global_batch": world * CFG["B"], "parallelism": f"dp{world}"}}
+               "max_elapsed": float(t), "config": {"global_batch": world * CFG["B"], "parallelism": f"dp{world}"},
+               "dist": info}
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.destroy_process_group()
@@ -467,7 +570,7 @@ def main():
     ap.add_argument("--micro-batch", type=int, default=None, help="gradient-accumulation slice (clips)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
-                    help="skip the secondary.config3_bf16 measurement the default run appends (same process, after the headline)")
+                    help="skip the secondary.config3_bf16 / config5_bf16 measurements the default run appends (same process, after the headline)")
     ap.add_argument("--no-kernel-timers", action="store_true", help="skip the per-launch HIP events (A/B runs)")
     ap.add_argument("--timer-every", type=int, default=10,
                     help="record the per-launch HIP events on every N-th step of the timed region (1 = every step).  The "
@@ -497,6 +600,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if os.environ.get("HWGAT_BENCH_DRYRUN") == "1":
         return dry_run(args, json_fd)
+    # each rank of a multi-GPU job goes to the CPUs next to its own GPU (sysfs only; before this process touches the GPU)
+    pin = None
+    if world > 1 or os.environ.get("HWGAT_FORCE_PIN") == "1":
+        pin = pin_rank_to_gpu_cpus(local, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
@@ -606,6 +713,11 @@ def main():
         barrier()
         elapsed_plain = time.perf_counter() - t0
 
+    dist_info = None
+    if use_dist:                                             # before the MAX: every rank's own step time, device, pinning
+        props = torch.cuda.get_device_properties(dev)
+        dist_info = dist_record(dist, world, f"{props.name} ({getattr(props, 'gcnArchName', '?')}) cuda:{local}",
+                                elapsed / args.steps * 1e3, pin)
     t = torch.tensor([elapsed, elapsed_plain or 0.0], device=dev, dtype=torch.float64)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -705,7 +817,7 @@ def main():
                                    + (", inputs collated from host samples every step (PCIe-inclusive, not the headline)"
                                       if args.from_host else ""),
                        "global_batch": world * c["B"], "parallelism": f"dp{world}"},
-            "roofline": roof, "roofline_end_to_end": roof_e2e,
+            "dist": dist_info, "roofline": roof, "roofline_end_to_end": roof_e2e,
             "kernels": kern, "other_hip_entry_points": others,
             "hip_kernel_ms_per_step": round(hip_ms / n_timed, 3), "kernel_timer_steps": n_timed,
             "loss": round(loss, 4),
@@ -716,10 +828,13 @@ def main():
             # the headline's model / optimizer / saved activations go first; its numbers above are final
             del step, opt, model
             torch.cuda.empty_cache()
-            try:
-                out["secondary"] = {"config3_bf16": secondary_config3(hw, train_mod, dev)}
-            except Exception as exc:                        # noqa: BLE001 -- the headline above is final and must be printed
-                out["secondary"] = {"config3_bf16": {"error": repr(exc)}}
+            out["secondary"] = {}
+            for name, fn in (("config3_bf16", secondary_config3), ("config5_bf16", secondary_config5)):
+                try:
+                    out["secondary"][name] = fn(hw, train_mod, dev)
+                except Exception as exc:                    # noqa: BLE001 -- the headline above is final and must be printed
+                    out["secondary"][name] = {"error": repr(exc)}
+                torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline and args.config != 5:
             # after the timed regions; the GPU is idle meanwhile
             out["cpu_baseline"] = cpu_baseline_wgate() if wgate else cpu_baseline(hgate=hgate)

@@ -213,7 +213,7 @@ def test_reducer_with_gradient_accumulation():
 def _run_bench(extra_env, *argv):
     import subprocess
     env = dict(os.environ, HWGAT_BENCH_DRYRUN="1", **extra_env)
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
         if k not in extra_env:
             env.pop(k, None)
     return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=env, capture_output=True,
@@ -233,6 +233,80 @@ def test_bench_parent_spawns_ranks_and_relays_one_json_line():
     assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1
     assert rec["config"]["global_batch"] == 128 and rec["config"]["parallelism"] == "dp2"
     assert abs(rec["max_elapsed"] - 0.002) < 1e-12          # MAX over ranks, not rank 0's own value
+    # the proof of what the process group was: gathered from every rank, not asserted by rank 0
+    d = rec["dist"]
+    assert d["backend"] == "gloo" and d["world_size_seen"] == 2 and d["distinct_processes"] == 2
+    assert d["devices"] == ["dry-run device of rank 0", "dry-run device of rank 1"]
+    assert d["step_ms_min"] < d["step_ms_max"]
+    assert len(d["cpu_pin"]) == 2 and all(p["pinned"] is False for p in d["cpu_pin"])   # no KFD topology in this container
+
+
+def _fake_sysfs(root, gpus, cpulists):
+    """a KFD topology + PCI tree like an 8-GPU MI355X host's: node 0.. = CPUs (no SIMDs), then one node per GPU"""
+    for i in range(2):
+        os.makedirs(os.path.join(root, f"class/kfd/kfd/topology/nodes/{i}"))
+        with open(os.path.join(root, f"class/kfd/kfd/topology/nodes/{i}/properties"), "w") as fh:
+            fh.write("cpu_cores_count 64\nsimd_count 0\nlocation_id 0\ndomain 0\n")
+    for g, (bus, cpus) in enumerate(zip(gpus, cpulists)):
+        node = os.path.join(root, f"class/kfd/kfd/topology/nodes/{2 + g}")
+        os.makedirs(node)
+        with open(os.path.join(node, "properties"), "w") as fh:
+            fh.write(f"cpu_cores_count 0\nsimd_count 1024\nlocation_id {bus << 8}\ndomain 0\n")
+        dev = os.path.join(root, f"bus/pci/devices/0000:{bus:02x}:00.0")
+        os.makedirs(dev)
+        with open(os.path.join(dev, "local_cpulist"), "w") as fh:
+            fh.write(cpus + "\n")
+
+
+def test_rank_cpu_pinning_reads_the_gpu_numa_node_from_sysfs(tmp_path, monkeypatch):
+    """bench.gpu_local_cpus / pin_rank_to_gpu_cpus: GPU index -> KFD node -> PCI address -> local_cpulist, the ranks
+    whose GPUs share a NUMA node split its CPUs in rank order; *_VISIBLE_DEVICES re-maps; nothing here touches a GPU."""
+    sys.path.insert(0, ROOT)
+    import bench
+    n_cpu = len(os.sched_getaffinity(0))
+    have = sorted(os.sched_getaffinity(0))
+    lo, hi = have[:n_cpu // 2], have[n_cpu // 2:]
+    as_list = lambda c: ",".join(str(v) for v in c)
+    root = str(tmp_path / "sys")
+    _fake_sysfs(root, [0x05, 0x15, 0x85, 0x95], [as_list(lo), as_list(lo), as_list(hi), as_list(hi)])
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    assert bench.gpu_local_cpus(0, root) == (lo, "0000:05:00.0")
+    assert bench.gpu_local_cpus(3, root) == (hi, "0000:95:00.0")
+    assert bench.gpu_local_cpus(4, root)[0] is None
+    assert bench._cpulist("0-3,8,10-11") == [0, 1, 2, 3, 8, 10, 11]
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "2,0")
+    assert bench.gpu_local_cpus(0, root) == (hi, "0000:85:00.0") and bench.gpu_local_cpus(1, root)[1] == "0000:05:00.0"
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    before = os.sched_getaffinity(0)
+    try:
+        if len(lo) >= 4:
+            rec = bench.pin_rank_to_gpu_cpus(1, 4, root)          # rank 1 shares the first node with rank 0: its second half
+            assert rec["pinned"] and rec["ranks_sharing_node"] == 2 and rec["pci"] == "0000:15:00.0"
+            assert os.sched_getaffinity(0) == set(lo[len(lo) // 2:2 * (len(lo) // 2)])
+            os.sched_setaffinity(0, before)
+        assert bench.pin_rank_to_gpu_cpus(0, 1, str(tmp_path / "nothing"))["pinned"] is False   # unreadable: left alone
+        assert os.sched_getaffinity(0) == before
+    finally:
+        os.sched_setaffinity(0, before)
+
+
+@pytest.mark.timeout(300)
+def test_bench_ranks_pin_themselves_in_the_dry_run(tmp_path):
+    """the spawned ranks (gloo dry run) pin themselves from a sysfs tree and the JSON line carries what each one did"""
+    import json
+    have = sorted(os.sched_getaffinity(0))
+    if len(have) < 4:
+        pytest.skip("needs 4 CPUs")
+    as_list = lambda c: ",".join(str(v) for v in c)
+    root = str(tmp_path / "sys")
+    _fake_sysfs(root, [0x05, 0x85], [as_list(have[:len(have) // 2]), as_list(have[len(have) // 2:])])
+    res = _run_bench({"HWGAT_BENCH_SYSFS": root}, "--gpus", "2", "--steps", "2", "--warmup", "1")
+    assert res.returncode == 0, res.stderr[-2000:]
+    d = json.loads(res.stdout.strip())["dist"]
+    pins = d["cpu_pin"]
+    assert [p["pinned"] for p in pins] == [True, True] and [p["pci"] for p in pins] == ["0000:05:00.0", "0000:85:00.0"]
+    assert pins[0]["last_cpu"] < pins[1]["first_cpu"] and pins[0]["cpus"] == len(have) // 2
 
 
 @pytest.mark.timeout(300)
