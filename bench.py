@@ -578,6 +578,9 @@ def main():
                          "headline step, but the 10-17 ms sibling-model steps are close to host-bound and a timed step "
                          "runs 1.3-2.3x longer, so the default times 2 of 20 steps")
     ap.add_argument("--eval-mode", action="store_true", help="deterministic fwd+bwd (no dropout / attention drop)")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture the whole train step (seed advance + fwd + loss + bwd + AdamW) in ONE HIP graph and replay it "
+                         "per step (train.GraphedTrainStep): same kernels, no per-launch host work; never the default headline")
     ap.add_argument("--from-host", action="store_true",
                     help="feed every step from host samples through collate.PinnedBatcher (pinned staging + async H2D): "
                          "the PCIe-inclusive rate DESIGN.md quotes; never the headline")
@@ -647,12 +650,17 @@ def main():
     model.train(not args.eval_mode)
     dist_mod.broadcast_parameters(model)
     reducer = dist_mod.GradReducer(model.parameters(), always_reduce=use_dist) if use_dist else None
-    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=5e-4, fused=True)
+    if args.graph and (args.micro_batch or args.eval_mode or use_dist):
+        sys.exit("bench.py --graph: one full-batch train-mode step on one GPU (no --micro-batch / --eval-mode / process group)")
+    opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=5e-4, fused=True, capturable=args.graph)
     step = train_mod.TrainStep(model, opt, reducer, micro_batch=args.micro_batch)
 
     g = torch.Generator(device=dev).manual_seed(7 + rank)
     x = torch.rand(c["B"], c["T"], c["J"], c["C"], device=dev, generator=g)
     y = torch.randint(0, c["nc"], (c["B"],), device=dev, generator=g)
+    eager_step = step
+    if args.graph:
+        step = train_mod.GraphedTrainStep(model, opt, x, y)
 
     def barrier():
         if use_dist:
@@ -678,6 +686,9 @@ def main():
     # of the timed region, not on all of them: an event pair costs ~3 us of stream time and 5-10 us of host time, and a
     # step has ~190-400 launches
     store, n_timed = {}, 0
+    graph_timers = args.graph and not args.no_kernel_timers      # per-launch events cannot sit inside a graph replay:
+    if args.graph:                                               # the kernel durations come from eager steps AFTER the timed region
+        args.no_kernel_timers = True
     if not args.no_kernel_timers:
         # one untimed step with the events on counts the launches of a step; the events the timed region will use are then
         # created BEFORE it (event creation, not recording, was most of what the per-launch timing cost)
@@ -697,6 +708,11 @@ def main():
         run_step()
     barrier()
     elapsed = time.perf_counter() - t0
+    if graph_timers:                                             # the same kernels, launched one by one, with events
+        HF.TIMERS = store
+        for _ in range(2):
+            eager_step(x, y)
+        n_timed = 2
     HF.TIMERS = store
     timers = HF.timers_summary()
     HF.TIMERS = None
@@ -814,6 +830,7 @@ def main():
                                    f"d_model={c['d0']} " + ("8 blocks" if wgate else "depths[2,2,4]") + f" classes={c['nc']}, "
                                    + ("eval-mode" if args.eval_mode else "train-mode drop 0.1")
                                    + (f", micro-batch {args.micro_batch}" if args.micro_batch else "")
+                                   + (", whole step replayed as one HIP graph" if args.graph else "")
                                    + (", inputs collated from host samples every step (PCIe-inclusive, not the headline)"
                                       if args.from_host else ""),
                        "global_batch": world * c["B"], "parallelism": f"dp{world}"},
@@ -823,7 +840,7 @@ def main():
             "loss": round(loss, 4),
         }
         default_run = (args.config == 2 and args.dtype == "f32" and args.model == "hwgate" and not args.eval_mode
-                       and not args.from_host and args.batch is None and args.micro_batch is None)
+                       and not args.from_host and args.batch is None and args.micro_batch is None and not args.graph)
         if world == 1 and default_run and not args.no_secondary:
             # the headline's model / optimizer / saved activations go first; its numbers above are final
             del step, opt, model

@@ -42,9 +42,24 @@ extern "C" {
  * HWGAT_ABI_VERSION of the header it was written against and refuse a mismatch (sl-hwgat_amd/_lib.py does).
  *   1000  round 1 (incl. hwgat_split3_bf16, hwgat_linear_nt_f32x9 -- removed in 2000)
  *   2000  round 2: *_ex linears, ln_fold / ln_finalize, epilogues 5 / 6, masked-gradient producers
- *   3000  round 3: see INTEGRATION.md section 3 */
-#define HWGAT_ABI_VERSION 3000
+ *   3000  round 3: see INTEGRATION.md section 3
+ *   4000  round 4: every entry point with a dropout seed takes `const uint32_t* seed_base` in front of `stream`;
+ *         hwgat_seed_set / hwgat_seed_advance; hwgat_is_lab_build */
+#define HWGAT_ABI_VERSION 4000
 int hwgat_abi_version(void);
+
+/* ---- dropout seeds (round 4).  Every `*_seed` argument below is a SITE seed, a host integer that identifies one dropout
+ * site of one block.  The seed a kernel hashes with is  site_seed + *seed_base  (32-bit wrap), where `seed_base` is a
+ * DEVICE word read when the kernel runs; NULL means 0 (the site seed is then the whole seed, as before ABI 4000).
+ * hwgat_seed_advance(state): state = 4 device words { step counter, base seed of the current step, initial seed, rank
+ * salt }; one thread does  counter += 1; base = initial * 0x9E3779B1 + counter * 0x85EBCA77 + salt * 0x27D4EB2F.  A model
+ * passes &state[1] as `seed_base` to every launch of a train step and runs hwgat_seed_advance once per step: no host
+ * integer of the step depends on the step number, so the whole step can be captured in a HIP graph and replayed with
+ * fresh masks (reference: nn.Dropout draws from the device generator, hwgat/models/HWGATE.py:27,116,133,135). */
+int hwgat_seed_advance(uint32_t* state, void* stream);
+/* the same state written from host integers (kernel arguments, no copy): state = { counter, base(counter), initial, salt }.
+ * The eager path of a model calls it once per train-mode forward; after it, hwgat_seed_advance continues from `counter`. */
+int hwgat_seed_set(uint32_t* state, uint32_t counter, uint32_t initial, uint32_t salt, void* stream);
 /* 1 for the kernel-lab build (`python sl-hwgat_amd/build.py --lab`, libhwgat_hip_lab.so: environment A/B switches compiled
  * in), 0 for the product library (reads no environment variables).  The lab tools assert 1 on the library they load. */
 int hwgat_is_lab_build(void);
@@ -72,7 +87,7 @@ int hwgat_debug_mfma_peak(float* out, int blocks, int iters, int n_acc, void* st
  *   hash mask of the fused linears (element index = flat index of `out`, seed `seed`). */
 int hwgat_embed_fwd(const float* x, const int32_t* idx, const float* bmat, const float* pe,
                     void* out, int B, int T, int J, int K, int C, int d0, int dtype,
-                    uint32_t seed, float drop_p, void* stream);
+                    uint32_t seed, float drop_p, const uint32_t* seed_base, void* stream);
 
 /* ---- LayerNorm over the last axis (HWGATE.py:203, 219, 353), eps 1e-5.
  *   x, y (N, d) `dtype`; gamma, beta (d) fp32; mean, rstd (N) fp32 (saved
@@ -94,14 +109,15 @@ int hwgat_ln_bwd(const void* dy, const void* x, const float* mean, const float* 
 int hwgat_ln_bwd_masked(const void* dy, const void* x, const float* mean, const float* rstd,
                         const float* gamma, const void* dres, void* dx, float* dgamma, float* dbeta,
                         int64_t N, int d, int dtype, void* dx_masked, uint32_t mask_seed, float mask_p,
-                        void* stream);
+                        const uint32_t* seed_base, void* stream);
 
 /* The same once more, and xn = LN(x) = xhat * gamma + beta written to `xn` (N, d) `dtype`: the layer input of the Linear
  * that follows this LayerNorm (HWGATE.py:203 -> :86, :219 -> :131), for that Linear's weight-gradient launch
  * (hwgat_linear_tn_*), which then needs no LayerNorm in its loaders.  dres required; dx_masked may be NULL. */
 int hwgat_ln_bwd_xn(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                     const float* beta, const void* dres, void* dx, float* dgamma, float* dbeta, int64_t N, int d,
-                    int dtype, void* dx_masked, uint32_t mask_seed, float mask_p, void* xn, void* stream);
+                    int dtype, void* dx_masked, uint32_t mask_seed, float mask_p, void* xn,
+                    const uint32_t* seed_base, void* stream);
 
 /* ---- a-4/a-5/a-6/a-10: fused window attention (MSA.forward, HWGATE.py:89-114)
  * over the body-part joint graph, with partition/roll/reverse as index math.
@@ -134,10 +150,10 @@ int hwgat_win_attn_bwd(const void* qkv, const void* dO, void* dqkv, const uint32
  * hwgat_win_attn_fwd / _bwd are these with drop_p = 0. */
 int hwgat_win_attn_fwd_drop(const void* qkv, void* o, const uint32_t* maskbits, const float* thr,
                             int B, int F, int nW, int nH, int hd, int shifted, int dtype,
-                            uint32_t drop_seed, float drop_p, void* stream);
+                            uint32_t drop_seed, float drop_p, const uint32_t* seed_base, void* stream);
 int hwgat_win_attn_bwd_drop(const void* qkv, const void* dO, void* dqkv, const uint32_t* maskbits,
                             const float* thr, int B, int F, int nW, int nH, int hd, int shifted,
-                            int dtype, uint32_t drop_seed, float drop_p, void* stream);
+                            int dtype, uint32_t drop_seed, float drop_p, const uint32_t* seed_base, void* stream);
 
 /* ---- (f) rank 3, sibling model HGATE: fused BLOCK attention (MSA.forward of
  * hwgat/models/HGATE.py:84-108) with block_partition / block_reverse / torch.roll
@@ -200,7 +216,7 @@ int hwgat_lnpool_bwd(const float* g, const void* x, const float* mean, const flo
 /* ... and dx_masked = dx * dropout-mask(mask_seed, element index), see hwgat_ln_bwd_masked (dx_masked may be NULL) */
 int hwgat_lnpool_bwd_masked(const float* g, const void* x, const float* mean, const float* rstd,
                             void* dx, int B, int n_tok, int d, int dtype, void* dx_masked, uint32_t mask_seed,
-                            float mask_p, void* stream);
+                            float mask_p, const uint32_t* seed_base, void* stream);
 
 /* ---- a-9: TemporalMerging (HWGATE.py:55-63): (B,F,K,d) -> (B,F/2,K,2d),
  * out[b,fi,k,tp*d+c] = in[b,2fi+tp,k,c]; `inverse` = 1 maps gradients back. */
@@ -209,7 +225,7 @@ int hwgat_merge(const void* in, void* out, int B, int F, int K, int d, int inver
 /* inverse mapping of a gradient plus a second, dropout-masked copy (mask of (mask_seed, un-merged element index)):
  * what the last block of a stage needs in front of its fc2 Dropout (HWGATE.py:135 backward) */
 int hwgat_unmerge_masked(const void* in, void* out, void* out_masked, int B, int F, int K, int d, int dtype,
-                         uint32_t mask_seed, float mask_p, void* stream);
+                         uint32_t mask_seed, float mask_p, const uint32_t* seed_base, void* stream);
 
 /* ---- a-6/a-7/a-8: fp32 Linear layers on f32 MFMA with fused elementwise work.
  * Replaces nn.Linear (HWGATE.py:86,115,131,134) + bias + GELU (:132) + Dropout
@@ -233,7 +249,8 @@ int hwgat_unmerge_masked(const void* in, void* out, void* out_masked, int B, int
 int hwgat_linear_nt_f32(const float* A, const float* W, const float* bias, float* C, int64_t M, int N,
                         int K, int pro, const float* mean, const float* rstd, const float* gamma,
                         const float* beta, uint32_t pro_seed, float pro_p, int epi, const float* res,
-                        float* C2, const float* aux, uint32_t epi_seed, float epi_p, void* stream);
+                        float* C2, const float* aux, uint32_t epi_seed, float epi_p,
+                        const uint32_t* seed_base, void* stream);
 
 /* The same launch for the two linears whose OUTPUT is the input of a LayerNorm (proj -> norm2, HWGATE.py:217-219;
  * fc2 -> the next block's norm1, :219 -> :203, through TemporalMerging :55-63 at a stage end).  Requires pro = 0,
@@ -249,7 +266,7 @@ int hwgat_linear_nt_f32_ex(const float* A, const float* W, const float* bias, fl
                            int K, int pro, const float* mean, const float* rstd, const float* gamma,
                            const float* beta, uint32_t pro_seed, float pro_p, int epi, const float* res,
                            float* C2, const float* aux, uint32_t epi_seed, float epi_p, float* stat_sum,
-                           float* stat_sq, int merge_F, int merge_K, void* stream);
+                           float* stat_sq, int merge_F, int merge_K, const uint32_t* seed_base, void* stream);
 
 /* Weights of a Linear that follows a LayerNorm (norm1 -> qkv, HWGATE.py:203-205 / :86; norm2 -> fc1, :219 / :131),
  * folded for pro = 3 of the NT launches:  Wf[n,k] = W[n,k] gamma[k] in `dtype` (HWGAT_F32 / HWGAT_BF16),
@@ -268,7 +285,7 @@ int hwgat_ln_finalize(float* sum_mean, float* sq_rstd, int64_t n, int d, void* s
  * mean != NULL: B is LayerNorm-ed on the fly, (B-mean[m])*rstd[m]*gamma[k]+beta[k]. */
 int hwgat_linear_tn_f32(const float* A, const float* B, float* dW, float* db, int64_t M, int N, int K,
                         uint32_t pro_seed, float pro_p, const float* mean, const float* rstd,
-                        const float* gamma, const float* beta, void* stream);
+                        const float* gamma, const float* beta, const uint32_t* seed_base, void* stream);
 
 /* ---- BASELINE config 3: the same two linears with bf16 activations / weights on
  * v_mfma_f32_32x32x16_bf16 (fp32 accumulate).  A, W, C, C2, res, aux are bf16; bias, LN
@@ -277,17 +294,18 @@ int hwgat_linear_tn_f32(const float* A, const float* B, float* dW, float* db, in
 int hwgat_linear_nt_bf16(const void* A, const void* W, const float* bias, void* C, int64_t M, int N, int K,
                          int pro, const float* mean, const float* rstd, const float* gamma,
                          const float* beta, uint32_t pro_seed, float pro_p, int epi, const void* res,
-                         void* C2, const void* aux, uint32_t epi_seed, float epi_p, void* stream);
+                         void* C2, const void* aux, uint32_t epi_seed, float epi_p,
+                         const uint32_t* seed_base, void* stream);
 /* hwgat_linear_nt_f32_ex for bf16 activations: the statistics are those of the bf16-rounded output values (what the
  * next LayerNorm reads), the merged store writes bf16. */
 int hwgat_linear_nt_bf16_ex(const void* A, const void* W, const float* bias, void* C, int64_t M, int N, int K,
                             int pro, const float* mean, const float* rstd, const float* gamma,
                             const float* beta, uint32_t pro_seed, float pro_p, int epi, const void* res,
                             void* C2, const void* aux, uint32_t epi_seed, float epi_p, float* stat_sum,
-                            float* stat_sq, int merge_F, int merge_K, void* stream);
+                            float* stat_sq, int merge_F, int merge_K, const uint32_t* seed_base, void* stream);
 int hwgat_linear_tn_bf16(const void* A, const void* B, float* dW, float* db, int64_t M, int N, int K,
                          uint32_t pro_seed, float pro_p, const float* mean, const float* rstd,
-                         const float* gamma, const float* beta, void* stream);
+                         const float* gamma, const float* beta, const uint32_t* seed_base, void* stream);
 /* The same for plain operands (no dropout mask, no LayerNorm) with a caller-owned workspace of
  * hwgat_linear_tn_bf16_ws_bytes(M, N, K) bytes: the partial dW tiles of the M slices are written as slabs and added in a
  * FIXED order by a second launch (no global atomics: ~20 us less per launch at the HWGAT shapes, dW bit-reproducible).
@@ -304,7 +322,8 @@ int hwgat_linear_tn_bf16_ws(const void* A, const void* B, float* dW, float* db, 
 int64_t hwgat_linear_tn_f32_ws_bytes(int64_t M, int N, int K);
 int hwgat_linear_tn_f32_ws(const float* A, const float* B, float* dW, float* db, int64_t M, int N, int K,
                            uint32_t pro_seed, float pro_p, const float* mean, const float* rstd,
-                           const float* gamma, const float* beta, float* ws, int64_t ws_bytes, void* stream);
+                           const float* gamma, const float* beta, float* ws, int64_t ws_bytes,
+                           const uint32_t* seed_base, void* stream);
 
 /* out[C,R] = in[R,C]^T (used on weights only) */
 int hwgat_transpose_f32(const float* in, float* out, int R, int C, void* stream);
@@ -324,7 +343,7 @@ typedef struct {
 int hwgat_weight_prep(const hwgat_prep_entry* table, int n, int total_blocks, int dtype, void* stream);
 
 /* the dropout mask the fused kernels use: out[i] = keep(seed, i) ? 1/(1-p) : 0 */
-int hwgat_dropout_mask_f32(float* out, int64_t n, uint32_t seed, float p, void* stream);
+int hwgat_dropout_mask_f32(float* out, int64_t n, uint32_t seed, float p, const uint32_t* seed_base, void* stream);
 
 #ifdef __cplusplus
 }

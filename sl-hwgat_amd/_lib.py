@@ -23,18 +23,20 @@ _U, _F = ctypes.c_uint32, ctypes.c_float
 _SIGS = {
     "hwgat_abi_version": [],
     "hwgat_is_lab_build": [],
+    "hwgat_seed_advance": [_P, _P],
+    "hwgat_seed_set": [_P, _U, _U, _U, _P],
     "hwgat_debug_mfma32x32x2": [_P, _P, _P, _P],
     "hwgat_debug_mfma_peak": [_P, _I, _I, _I, _P],
-    "hwgat_embed_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _U, _F, _P],
+    "hwgat_embed_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _U, _F, _P, _P],
     "hwgat_ln_fwd": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
     "hwgat_ln_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P],
-    "hwgat_ln_bwd_masked": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _U, _F, _P],
-    "hwgat_ln_bwd_xn": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _U, _F, _P, _P],
+    "hwgat_ln_bwd_masked": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _U, _F, _P, _P],
+    "hwgat_ln_bwd_xn": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _U, _F, _P, _P, _P],
     "hwgat_win_attn_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "hwgat_win_attn_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "hwgat_weight_prep": [_P, _I, _I, _I, _P],
-    "hwgat_win_attn_fwd_drop": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _U, _F, _P],
-    "hwgat_win_attn_bwd_drop": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _U, _F, _P],
+    "hwgat_win_attn_fwd_drop": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _U, _F, _P, _P],
+    "hwgat_win_attn_bwd_drop": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _U, _F, _P, _P],
     "hwgat_blk_attn_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "hwgat_blk_attn_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "hwgat_band_attn_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
@@ -44,23 +46,23 @@ _SIGS = {
     "hwgat_lnpool_partial_rows": [_I, _I],
     "hwgat_lnpool_fwd_det": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
     "hwgat_lnpool_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
-    "hwgat_lnpool_bwd_masked": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _U, _F, _P],
-    "hwgat_unmerge_masked": [_P, _P, _P, _I, _I, _I, _I, _I, _U, _F, _P],
+    "hwgat_lnpool_bwd_masked": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _U, _F, _P, _P],
+    "hwgat_unmerge_masked": [_P, _P, _P, _I, _I, _I, _I, _I, _U, _F, _P, _P],
     "hwgat_merge": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
-    "hwgat_linear_nt_f32": [_P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _P, _U, _F, _I, _P, _P, _P, _U, _F, _P],
-    "hwgat_linear_nt_f32_ex": [_P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _P, _U, _F, _I, _P, _P, _P, _U, _F, _P, _P, _I, _I, _P],
-    "hwgat_linear_nt_bf16_ex": [_P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _P, _U, _F, _I, _P, _P, _P, _U, _F, _P, _P, _I, _I, _P],
+    "hwgat_linear_nt_f32": [_P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _P, _U, _F, _I, _P, _P, _P, _U, _F, _P, _P],
+    "hwgat_linear_nt_f32_ex": [_P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _P, _U, _F, _I, _P, _P, _P, _U, _F, _P, _P, _I, _I, _P, _P],
+    "hwgat_linear_nt_bf16_ex": [_P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _P, _U, _F, _I, _P, _P, _P, _U, _F, _P, _P, _I, _I, _P, _P],
     "hwgat_ln_finalize": [_P, _P, _L, _I, _P],
     "hwgat_ln_fold": [_P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _P],
-    "hwgat_linear_tn_f32": [_P, _P, _P, _P, _L, _I, _I, _U, _F, _P, _P, _P, _P, _P],
-    "hwgat_linear_nt_bf16": [_P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _P, _U, _F, _I, _P, _P, _P, _U, _F, _P],
-    "hwgat_linear_tn_bf16": [_P, _P, _P, _P, _L, _I, _I, _U, _F, _P, _P, _P, _P, _P],
+    "hwgat_linear_tn_f32": [_P, _P, _P, _P, _L, _I, _I, _U, _F, _P, _P, _P, _P, _P, _P],
+    "hwgat_linear_nt_bf16": [_P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _P, _U, _F, _I, _P, _P, _P, _U, _F, _P, _P],
+    "hwgat_linear_tn_bf16": [_P, _P, _P, _P, _L, _I, _I, _U, _F, _P, _P, _P, _P, _P, _P],
     "hwgat_linear_tn_f32_ws_bytes": [_L, _I, _I],
-    "hwgat_linear_tn_f32_ws": [_P, _P, _P, _P, _L, _I, _I, _U, _F, _P, _P, _P, _P, _P, _L, _P],
+    "hwgat_linear_tn_f32_ws": [_P, _P, _P, _P, _L, _I, _I, _U, _F, _P, _P, _P, _P, _P, _L, _P, _P],
     "hwgat_linear_tn_bf16_ws_bytes": [_L, _I, _I],
     "hwgat_linear_tn_bf16_ws": [_P, _P, _P, _P, _L, _I, _I, _P, _L, _P],
     "hwgat_transpose_f32": [_P, _P, _I, _I, _P],
-    "hwgat_dropout_mask_f32": [_P, _L, _U, _F, _P],
+    "hwgat_dropout_mask_f32": [_P, _L, _U, _F, _P, _P],
 }
 _lib = None
 

@@ -75,7 +75,7 @@ class _FusedBlock(torch.autograd.Function):
         # xc: the "carrier" the producing block handed over with x (or None).  It has no data (a 1-element tensor
         # expanded to x's shape); its only purpose is that THIS block's backward can return, as its gradient, the masked
         # copy of dx that the producing block needs in front of its fc2 dropout (cfg `up` = that dropout's seed).
-        bits, n_heads, shifted, p, seeds, kind, want_stats, merge_out, up, carry_out, book, deterministic, attn_p, prep = cfg
+        bits, n_heads, shifted, p, seeds, kind, want_stats, merge_out, up, carry_out, book, deterministic, attn_p, prep, sb = cfg
         ctx.set_materialize_grads(False)          # an unused carrier gradient arrives as None, not as a zero tensor
         B, F, K, d = x.shape
         dt = x.dtype                              # fp32, or bf16 activations with fp32 master weights
@@ -99,23 +99,23 @@ class _FusedBlock(torch.autograd.Function):
             m1, r1 = HF.ln_stats(x, n1w, n1b)
         qkv = HF.linear_nt_ln(x, wqkv, bqkv, (m1, r1, n1w, n1b), folded=prep.get("qkv_f"))
         o = torch.empty_like(x)
-        HF.attn_fwd(kind, qkv, o, bits, thr, n_heads, shifted, (seeds[3], attn_p) if attn_p > 0.0 else None)
+        HF.attn_fwd(kind, qkv, o, bits, thr, n_heads, shifted, (seeds[3], attn_p, sb) if attn_p > 0.0 else None)
         wp_c = prep["wp_c"] if "wp_c" in prep else cw(wp)
         w2_c = prep["w2_c"] if "w2_c" in prep else cw(w2)
         if fuse:
-            y, m2, r2 = HF.linear_nt(o, wp_c, bp, epi=HF.EPI_BIAS_DROP_RES, res=x, epi_seed=seeds[0], epi_p=p, stats=True)
+            y, m2, r2 = HF.linear_nt(o, wp_c, bp, epi=HF.EPI_BIAS_DROP_RES, res=x, epi_seed=seeds[0], epi_p=p, stats=True, seed_base=sb)
         else:
-            y = HF.linear_nt(o, wp_c, bp, epi=HF.EPI_BIAS_DROP_RES, res=x, epi_seed=seeds[0], epi_p=p)
+            y = HF.linear_nt(o, wp_c, bp, epi=HF.EPI_BIAS_DROP_RES, res=x, epi_seed=seeds[0], epi_p=p, seed_base=sb)
             m2, r2 = HF.ln_stats(y, n2w, n2b)
         # h1 here is gelu'(pre-activation) * dropout mask, the factor the backward multiplies by (EPI_BIAS_GELU_DROP_G)
         u, h1 = HF.linear_nt_ln(y, w1, b1, (m2, r2, n2w, n2b), epi=HF.EPI_BIAS_GELU_DROP_G, epi_seed=seeds[1], epi_p=p,
-                                folded=prep.get("w1_f"))
+                                folded=prep.get("w1_f"), seed_base=sb)
         merged = bool(merge_out and fuse)
         if fuse and (want_stats or merged):
             out, mo, ro = HF.linear_nt(u, w2_c, b2, epi=HF.EPI_BIAS_DROP_RES, res=y, epi_seed=seeds[2], epi_p=p,
-                                       stats=True, merge=(F, K) if merged else None)
+                                       stats=True, merge=(F, K) if merged else None, seed_base=sb)
         else:
-            out = HF.linear_nt(u, w2_c, b2, epi=HF.EPI_BIAS_DROP_RES, res=y, epi_seed=seeds[2], epi_p=p)
+            out = HF.linear_nt(u, w2_c, b2, epi=HF.EPI_BIAS_DROP_RES, res=y, epi_seed=seeds[2], epi_p=p, seed_base=sb)
             mo = ro = torch.empty(0, device=x.device)
         ctx.save_for_backward(x, thr, n1w, n1b, wqkv, wp, n2w, n2b, w1, w2, m1, r1, qkv, o, y, m2, r2, h1, u)
         ctx.cfg = cfg
@@ -135,7 +135,7 @@ class _FusedBlock(torch.autograd.Function):
     def backward(ctx, dout, _dmo, _dro, doutm=None):
         x, thr, n1w, n1b, wqkv, wp, n2w, n2b, w1, w2, m1, r1, qkv, o, y, m2, r2, h1, u = ctx.saved_tensors
         bits, n_heads, shifted, p, seeds, kind = ctx.cfg[:6]
-        up, attn_p, prep = ctx.cfg[8], ctx.cfg[12], ctx.cfg[13] or {}
+        up, attn_p, prep, sb = ctx.cfg[8], ctx.cfg[12], ctx.cfg[13] or {}, ctx.cfg[14]
         if prep and ("w2T" not in prep or prep["w2T"].dtype != x.dtype):
             prep = {}
 
@@ -152,7 +152,7 @@ class _FusedBlock(torch.autograd.Function):
             if p > 0.0 and HF.MASK_ONCE >= 2 and d >= HF.MASK_ONCE_MIN_D:   # ... and once more multiplied by this block's fc2-dropout mask
                 doutm = torch.empty_like(x)
                 HF.call("hwgat_unmerge_masked", HF.ptr(dout), HF.ptr(nat), HF.ptr(doutm), B, F, K, d, HF.dtype_code(dout),
-                        seeds[2] & 0xFFFFFFFF, float(p), HF.stream())
+                        seeds[2] & 0xFFFFFFFF, float(p), HF.ptr(sb), HF.stream())
             else:
                 doutm = None
                 HF.call("hwgat_merge", HF.ptr(dout), HF.ptr(nat), B, F, K, d, 1, HF.dtype_code(dout), HF.stream())
@@ -176,9 +176,9 @@ class _FusedBlock(torch.autograd.Function):
             dwq.run(lambda: HF.linear_tn(doutm, u, dw2, db2))
             d_h1 = HF.linear_nt(doutm, wT("w2T", w2), None, epi=HF.EPI_MUL_AUX, aux=h1)
         else:
-            dwq.run(lambda: HF.linear_tn(dout, u, dw2, db2, pro_seed=seeds[2], pro_p=p))
+            dwq.run(lambda: HF.linear_tn(dout, u, dw2, db2, pro_seed=seeds[2], pro_p=p, seed_base=sb))
             d_h1 = HF.linear_nt(dout, wT("w2T", w2), None, pro=HF.PRO_DROP, pro_seed=seeds[2], pro_p=p,
-                                epi=HF.EPI_MUL_AUX, aux=h1)
+                                epi=HF.EPI_MUL_AUX, aux=h1, seed_base=sb)
         xn_path = HF.dw_wants_xn(x)               # LN(x) written by the LayerNorm backward for the dW launches (bf16, d % 256 == 0)
         if not xn_path:
             dwq.run(lambda: HF.linear_tn(d_h1, y, dw1, db1, ln=(m2, r2, n2w, n2b)))
@@ -186,10 +186,10 @@ class _FusedBlock(torch.autograd.Function):
         # ---- attention branch: y = x + drop1(o Wp^T + bp)
         if p > 0.0 and HF.MASK_ONCE >= 1 and d >= HF.MASK_ONCE_MIN_D:
             if xn_path:
-                d_y, d_ym, yn = HF.ln_backward(d_z, y, m2, r2, n2w, dout, dn2w, dn2b, mask=(seeds[0], p), beta=n2b)
+                d_y, d_ym, yn = HF.ln_backward(d_z, y, m2, r2, n2w, dout, dn2w, dn2b, mask=(seeds[0], p), beta=n2b, seed_base=sb)
                 dwq.run(lambda: HF.linear_tn(d_h1, yn, dw1, db1))
             else:
-                d_y, d_ym = HF.ln_backward(d_z, y, m2, r2, n2w, dout, dn2w, dn2b, mask=(seeds[0], p))   # + shortcut; and dropmask1 * d_y
+                d_y, d_ym = HF.ln_backward(d_z, y, m2, r2, n2w, dout, dn2w, dn2b, mask=(seeds[0], p), seed_base=sb)   # + shortcut; and dropmask1 * d_y
             dwq.run(lambda: HF.linear_tn(d_ym, o, dwp, dbp))
             d_o = HF.linear_nt(d_ym, wT("wpT", wp), None, epi=HF.EPI_NONE, out=d_z)
         else:
@@ -198,11 +198,11 @@ class _FusedBlock(torch.autograd.Function):
                 dwq.run(lambda: HF.linear_tn(d_h1, yn, dw1, db1))
             else:
                 d_y = HF.ln_backward(d_z, y, m2, r2, n2w, dout, dn2w, dn2b)          # + shortcut gradient
-            dwq.run(lambda: HF.linear_tn(d_y, o, dwp, dbp, pro_seed=seeds[0], pro_p=p))
+            dwq.run(lambda: HF.linear_tn(d_y, o, dwp, dbp, pro_seed=seeds[0], pro_p=p, seed_base=sb))
             d_o = HF.linear_nt(d_y, wT("wpT", wp), None, pro=HF.PRO_DROP, pro_seed=seeds[0], pro_p=p,
-                               epi=HF.EPI_NONE, out=d_z)
+                               epi=HF.EPI_NONE, out=d_z, seed_base=sb)
         dqkv = torch.empty_like(qkv)
-        HF.attn_bwd(kind, qkv, d_o, dqkv, bits, thr, n_heads, shifted, (seeds[3], attn_p) if attn_p > 0.0 else None)
+        HF.attn_bwd(kind, qkv, d_o, dqkv, bits, thr, n_heads, shifted, (seeds[3], attn_p, sb) if attn_p > 0.0 else None)
         if not xn_path:
             dwq.run(lambda: HF.linear_tn(dqkv, x, dwqkv, dbqkv, ln=(m1, r1, n1w, n1b)))
         d_xn = HF.linear_nt(dqkv, wT("wqkvT", wqkv), None, epi=HF.EPI_NONE, out=d_o)
@@ -211,9 +211,9 @@ class _FusedBlock(torch.autograd.Function):
         dxm = None
         if ctx.send_up:           # the block that produced x gets dropmask3(its seed) * dx through the carrier's gradient
             if xn_path:
-                dx, dxm, xn = HF.ln_backward(d_xn, x, m1, r1, n1w, d_y, dn1w, dn1b, mask=up, beta=n1b)
+                dx, dxm, xn = HF.ln_backward(d_xn, x, m1, r1, n1w, d_y, dn1w, dn1b, mask=up, beta=n1b, seed_base=sb)
             else:
-                dx, dxm = HF.ln_backward(d_xn, x, m1, r1, n1w, d_y, dn1w, dn1b, mask=up)
+                dx, dxm = HF.ln_backward(d_xn, x, m1, r1, n1w, d_y, dn1w, dn1b, mask=up, seed_base=sb)
         elif xn_path:
             dx, xn = HF.ln_backward(d_xn, x, m1, r1, n1w, d_y, dn1w, dn1b, beta=n1b)
         else:
@@ -228,7 +228,7 @@ class _FusedBlock(torch.autograd.Function):
 
 def fused_block(x, thr, blk, bits, n_heads, shifted, p, seeds, kind="win", stats=None, want_stats=False,
                 merge_out=False, return_stats=False, carrier=None, up=None, carry_out=False, return_carrier=None,
-                book=None, deterministic=False, attn_p=0.0, prep=None):
+                book=None, deterministic=False, attn_p=0.0, prep=None, seed_base=None):
     """x (B,F,K,d) contiguous; `blk` holds norm1/attn.qkv/attn.proj/norm2/ff.fc1/ff.fc2.
     `kind`: 'win' = HWGATE part-window attention, 'blk' = HGATE block attention (thr must be None).
     `stats` = (mean, rstd) of the rows of x if the producer already has them; `want_stats`: have the fc2 epilogue produce
@@ -241,6 +241,7 @@ def fused_block(x, thr, blk, bits, n_heads, shifted, p, seeds, kind="win", stats
     sides need the same `book` (functional.CarryBook of this forward call), without one no carrier is made or used.
     `attn_p`: attention dropout rate (reference HWGATE.py:78,112; 'win' only, needs `thr` and a fourth seed, seeds[3]).
     `prep`: this block's entry of the call's functional.WeightPrep (derived weight copies made by one launch per call).
+    `seed_base`: 1-element device tensor added to every site seed when a kernel runs (functional.embed), or None.
     `deterministic`: bit-reproducible forward (eval mode): statistics / merged store stay in the epilogue only where a
     row collects at most two atomic partials.
     Returns out, or (out, (mean, rstd) or None) with `return_stats`; with `carry_out` / `return_carrier` the carrier (or None) is appended."""
@@ -253,7 +254,7 @@ def fused_block(x, thr, blk, bits, n_heads, shifted, p, seeds, kind="win", stats
         blk.ff.fc1.weight, blk.ff.fc1.bias, blk.ff.fc2.weight, blk.ff.fc2.bias,
         (bits, n_heads, shifted, float(p), tuple(int(s) for s in seeds), kind, bool(want_stats), bool(merge_out),
          (int(up[0]), float(up[1])) if (up is not None and carrier is not None) else None, bool(carry_out),
-         book, bool(deterministic), float(attn_p), prep))
+         book, bool(deterministic), float(attn_p), prep, seed_base))
     oc = oc if oc.numel() else None
     if return_carrier is None:
         return_carrier = bool(carry_out)

@@ -26,6 +26,14 @@ inline const char* lab_env(const char* name) { return getenv(name); }
 constexpr const char* lab_env(const char*) { return nullptr; }
 #endif
 
+// Dropout seeds.  Every `*_seed` argument of the C ABI is a SITE seed (a host integer, fixed for a model / block / dropout
+// site); the seed a kernel hashes with is  site_seed + *seed_base  where `seed_base` is a DEVICE word read when the kernel
+// runs (NULL = 0).  A train step captured in a HIP graph therefore replays with fresh masks: hwgat_seed_advance, a node of
+// the same graph, rewrites the word before the kernels that read it.  Resolved once at kernel entry (a scalar load).
+__device__ __forceinline__ uint32_t seed_base_of(const uint32_t* seed_base) { return seed_base ? *seed_base : 0u; }
+#define HWGAT_RESOLVE_SEEDS2(p) do { const uint32_t sb__ = seed_base_of((p).seed_base); (p).pro_seed += sb__; (p).epi_seed += sb__; } while (0)
+#define HWGAT_RESOLVE_SEED1(p) do { (p).pro_seed += seed_base_of((p).seed_base); } while (0)
+
 #define HWGAT_LAUNCH_CHECK()                          \
     do {                                              \
         hipError_t e__ = hipGetLastError();           \

@@ -18,7 +18,9 @@ template <typename T, int C>
 __global__ __launch_bounds__(256) void embed_fwd_k(const float* __restrict__ x, const int32_t* __restrict__ idx,
                                                    const float* __restrict__ bmat, const float* __restrict__ pe,
                                                    T* __restrict__ out, int64_t n_tok, int T_, int J, int K,
-                                                   int d0, uint32_t seed, float drop_p) {
+                                                   int d0, uint32_t seed, float drop_p,
+                                                   const uint32_t* __restrict__ sbase) {
+    seed += seed_base_of(sbase);
     const int half = d0 >> 1;
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -85,7 +87,9 @@ __global__ __launch_bounds__(256) void embed_fwd_k(const float* __restrict__ x, 
 template <typename T>
 __global__ __launch_bounds__(256) void merge_k(const T* __restrict__ in, T* __restrict__ out, int64_t n_chunks,
                                                int F, int K, int d, int inverse, T* __restrict__ out_m = nullptr,
-                                               uint32_t mseed = 0, float mp = 0.f) {
+                                               uint32_t mseed = 0, float mp = 0.f,
+                                               const uint32_t* __restrict__ sbase = nullptr) {
+    mseed += seed_base_of(sbase);
     constexpr int EPV = io<T>::EPV;
     const int cpr = d / EPV;                                   // chunks per input row
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -135,14 +139,14 @@ __global__ __launch_bounds__(256) void merge_k(const T* __restrict__ in, T* __re
 
 extern "C" int hwgat_embed_fwd(const float* x, const int32_t* idx, const float* bmat, const float* pe, void* out,
                                int B, int T, int J, int K, int C, int d0, int dtype, uint32_t seed, float drop_p,
-                               void* stream) {
+                               const uint32_t* seed_base, void* stream) {
     if (!x || !bmat || !out || B <= 0 || T <= 0 || J <= 0 || K <= 0 || drop_p < 0.f || drop_p >= 1.f) return HWGAT_EINVAL;
     if (d0 <= 0 || (d0 & 1) || (!idx && J != K) || (C != 2 && C != 3)) return HWGAT_ESHAPE;
     hipStream_t st = (hipStream_t)stream;
     const int64_t n_tok = (int64_t)B * T * K;
     const int64_t n_bt = (int64_t)B * T;                      // one wave per (clip, frame) row of K tokens, grid-stride beyond
     const int grid = (int)(n_bt / 4 < 4096 ? (n_bt + 3) / 4 : 4096);
-#define GO(TT, CC) embed_fwd_k<TT, CC><<<grid, 256, 0, st>>>(x, idx, bmat, pe, (TT*)out, n_tok, T, J, K, d0, seed, drop_p)
+#define GO(TT, CC) embed_fwd_k<TT, CC><<<grid, 256, 0, st>>>(x, idx, bmat, pe, (TT*)out, n_tok, T, J, K, d0, seed, drop_p, seed_base)
     if (dtype == HWGAT_F32) { if (C == 2) GO(float, 2); else GO(float, 3); }
     else if (dtype == HWGAT_BF16) { if (C == 2) GO(bf16_t, 2); else GO(bf16_t, 3); }
     else return HWGAT_EDTYPE;
@@ -166,7 +170,7 @@ extern "C" int hwgat_merge(const void* in, void* out, int B, int F, int K, int d
 }
 
 extern "C" int hwgat_unmerge_masked(const void* in, void* out, void* out_masked, int B, int F, int K, int d, int dtype,
-                                    uint32_t mask_seed, float mask_p, void* stream) {
+                                    uint32_t mask_seed, float mask_p, const uint32_t* seed_base, void* stream) {
     if (!in || !out || !out_masked || B <= 0 || F <= 0 || K <= 0 || d <= 0) return HWGAT_EINVAL;
     if (mask_p <= 0.f || mask_p >= 1.f) return HWGAT_EINVAL;
     if (F & 1) return HWGAT_ESHAPE;
@@ -176,8 +180,35 @@ extern "C" int hwgat_unmerge_masked(const void* in, void* out, void* out_masked,
     if (d % epv) return HWGAT_ESHAPE;
     const int64_t n = (int64_t)B * F * K * (d / epv);
     const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    if (dtype == HWGAT_F32) merge_k<float><<<grid, 256, 0, st>>>((const float*)in, (float*)out, n, F, K, d, 1, (float*)out_masked, mask_seed, mask_p);
-    else merge_k<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)in, (bf16_t*)out, n, F, K, d, 1, (bf16_t*)out_masked, mask_seed, mask_p);
+    if (dtype == HWGAT_F32) merge_k<float><<<grid, 256, 0, st>>>((const float*)in, (float*)out, n, F, K, d, 1, (float*)out_masked, mask_seed, mask_p, seed_base);
+    else merge_k<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)in, (bf16_t*)out, n, F, K, d, 1, (bf16_t*)out_masked, mask_seed, mask_p, seed_base);
+    HWGAT_LAUNCH_CHECK();
+}
+
+// The device-resident dropout seed of a model: state[0] = step counter, state[1] = base seed of the current step (what the
+// kernels read through `seed_base`), state[2] = the model's initial seed, state[3] = rank salt.  One thread; as a node of
+// a captured train step it makes every replay draw fresh masks without any host-side value in the graph.
+namespace {
+__global__ void seed_advance_k(uint32_t* __restrict__ state) {
+    const uint32_t n = state[0] + 1u;
+    state[0] = n;
+    state[1] = state[2] * 0x9E3779B1u + n * 0x85EBCA77u + state[3] * 0x27D4EB2Fu;
+}
+__global__ void seed_set_k(uint32_t* __restrict__ state, uint32_t counter, uint32_t initial, uint32_t salt) {
+    state[0] = counter;
+    state[1] = initial * 0x9E3779B1u + counter * 0x85EBCA77u + salt * 0x27D4EB2Fu;
+    state[2] = initial;
+    state[3] = salt;
+}
+}  // namespace
+extern "C" int hwgat_seed_set(uint32_t* state, uint32_t counter, uint32_t initial, uint32_t salt, void* stream) {
+    if (!state) return HWGAT_EINVAL;
+    seed_set_k<<<1, 1, 0, (hipStream_t)stream>>>(state, counter, initial, salt);
+    HWGAT_LAUNCH_CHECK();
+}
+extern "C" int hwgat_seed_advance(uint32_t* state, void* stream) {
+    if (!state) return HWGAT_EINVAL;
+    seed_advance_k<<<1, 1, 0, (hipStream_t)stream>>>(state);
     HWGAT_LAUNCH_CHECK();
 }
 

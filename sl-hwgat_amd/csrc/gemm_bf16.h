@@ -15,6 +15,7 @@ struct NtArgsB {
     // exactly as NtArgs in gemm_f32.h
     float* stat_sum; float* stat_sq;
     int mg_F, mg_K;
+    const uint32_t* seed_base;   // device word added to the site seeds at kernel entry (NULL = 0), see common.h
 };
 
 // output row m -> row of the merged (B, F/2, K, 2N) tensor for a lane that walks rows m, m + step, ... of one tile:
@@ -66,6 +67,7 @@ struct TnArgsB {
     int n_split; int64_t rows_per_split;
     uint32_t pro_seed; float pro_p;
     int64_t row0;          // see NtArgsB
+    const uint32_t* seed_base;   // device word added to the site seeds at kernel entry (NULL = 0), see common.h
 };
 
 // defined in gemm_bf16_tn256.hip: 256x256 dW tiles; N % 256 == K % 256 == M % 32 == 0

@@ -40,6 +40,7 @@ struct SlabIt {
 // family, gemm_f32.hip): clamped loads, guarded stores, dropout hashed with the global row index.
 template <int PRO, int EPI, typename C, bool RAGGED = false, int STAT = 0>      // STAT: see gemm_nt256_bf16_k
 __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt_bf16_k(NtArgsB p) {
+    HWGAT_RESOLVE_SEEDS2(p);
     constexpr int BM = C::BM, BN = C::BN, BK = C::BK, LDT = C::LDT, PA = C::PA, PW = C::PW, RPP = C::RPP;
     constexpr int TMW = C::TMW, TNW = C::TNW;
     __shared__ __attribute__((aligned(16))) bf16_t sm[2 * (BM + BN) * LDT];   // [buf][A rows | W rows][LDT]
@@ -352,6 +353,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* tile, int m_base, int c0
 
 template <int PRO, bool BLN, bool RAGGED = false>
 __global__ __launch_bounds__(256, 3) void gemm_tn_bf16_k(TnArgsB p) {
+    HWGAT_RESOLVE_SEED1(p);
     __shared__ __attribute__((aligned(16))) bf16_t sm[2 * 2 * TMB * LDW];    // [buf][A|B][32][160]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane & 31, hh = lane >> 5;
@@ -543,7 +545,7 @@ extern "C" int hwgat_linear_nt_bf16_ex(const void* A, const void* W, const float
                                        int K, int pro, const float* mean, const float* rstd, const float* gamma,
                                        const float* beta, uint32_t pro_seed, float pro_p, int epi, const void* res,
                                        void* C2, const void* aux, uint32_t epi_seed, float epi_p, float* stat_sum,
-                                       float* stat_sq, int merge_F, int merge_K, void* stream) {
+                                       float* stat_sq, int merge_F, int merge_K, const uint32_t* seed_base, void* stream) {
     if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) return HWGAT_EINVAL;
     if (N % 128 || K % 64 || ((M + 127) / 128) * (int64_t)(N / 128) > 0x7fffffff) return HWGAT_ESHAPE;   // any M
     if ((pro == PRO_LN || pro == PRO_LN_FOLD) && (!mean || !rstd || !gamma || !beta)) return HWGAT_EINVAL;
@@ -564,12 +566,13 @@ extern "C" int hwgat_linear_nt_bf16_ex(const void* A, const void* W, const float
     }
     NtArgsB a{(const bf16_t*)A, (const bf16_t*)W, bias, (bf16_t*)C, (bf16_t*)C2, (const bf16_t*)res,
               (const bf16_t*)aux, mean, rstd, gamma, beta, M, N, K, pro_seed, epi_seed, pro_p, epi_p, 0, stat_sum, stat_sq, merge_K > 0 ? merge_F : 0, merge_K > 0 ? merge_K : 0};
+    a.seed_base = seed_base;
     hipStream_t st = (hipStream_t)stream;
     const int64_t m_bulk = M / 128 * 128;                       // ragged token count: bulk launch + RAGGED tail launch
     if (m_bulk != M) {
         if (m_bulk) {
             const int rc = hwgat_linear_nt_bf16(A, W, bias, C, m_bulk, N, K, pro, mean, rstd, gamma, beta, pro_seed, pro_p,
-                                                epi, res, C2, aux, epi_seed, epi_p, stream);
+                                                epi, res, C2, aux, epi_seed, epi_p, seed_base, stream);
             if (rc) return rc;
         }
         const NtArgsB t = nt_rows_b(a, m_bulk, M - m_bulk);
@@ -619,9 +622,10 @@ extern "C" int hwgat_linear_nt_bf16_ex(const void* A, const void* W, const float
 extern "C" int hwgat_linear_nt_bf16(const void* A, const void* W, const float* bias, void* C, int64_t M, int N,
                                     int K, int pro, const float* mean, const float* rstd, const float* gamma,
                                     const float* beta, uint32_t pro_seed, float pro_p, int epi, const void* res,
-                                    void* C2, const void* aux, uint32_t epi_seed, float epi_p, void* stream) {
+                                    void* C2, const void* aux, uint32_t epi_seed, float epi_p,
+                                    const uint32_t* seed_base, void* stream) {
     return hwgat_linear_nt_bf16_ex(A, W, bias, C, M, N, K, pro, mean, rstd, gamma, beta, pro_seed, pro_p, epi, res, C2, aux,
-                                   epi_seed, epi_p, nullptr, nullptr, 0, 0, stream);
+                                   epi_seed, epi_p, nullptr, nullptr, 0, 0, seed_base, stream);
 }
 
 extern "C" int64_t hwgat_linear_tn_bf16_ws_bytes(int64_t M, int N, int K) { return 4 * hwgat_tn8w_bf16_ws_floats(M, N, K); }
@@ -634,14 +638,14 @@ extern "C" int hwgat_linear_tn_bf16_ws(const void* A, const void* B, float* dW, 
     if (!A || !B || !dW || M <= 0 || N <= 0 || K <= 0) return HWGAT_EINVAL;
     const int64_t need = hwgat_linear_tn_bf16_ws_bytes(M, N, K);
     if (need == 0 || !ws || ws_bytes < need)
-        return hwgat_linear_tn_bf16(A, B, dW, db, M, N, K, 0, 0.f, nullptr, nullptr, nullptr, nullptr, stream);
+        return hwgat_linear_tn_bf16(A, B, dW, db, M, N, K, 0, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
     TnArgsB a{(const bf16_t*)A, (const bf16_t*)B, dW, db, nullptr, nullptr, nullptr, nullptr, M, N, K, 1, M, 0, 0.f, 0};
     return hwgat_launch_tn8w_bf16(a, (hipStream_t)stream, ws);
 }
 
 extern "C" int hwgat_linear_tn_bf16(const void* A, const void* B, float* dW, float* db, int64_t M, int N, int K,
                                     uint32_t pro_seed, float pro_p, const float* mean, const float* rstd,
-                                    const float* gamma, const float* beta, void* stream) {
+                                    const float* gamma, const float* beta, const uint32_t* seed_base, void* stream) {
     if (!A || !B || !dW || M <= 0 || N <= 0 || K <= 0) return HWGAT_EINVAL;
     if (mean && (!rstd || !gamma || !beta)) return HWGAT_EINVAL;
     if (N % 128 || K % 128) return HWGAT_ESHAPE;                 // any M
@@ -649,12 +653,13 @@ extern "C" int hwgat_linear_tn_bf16(const void* A, const void* B, float* dW, flo
     const int64_t m_bulk = M / TMB * TMB;
     if (m_bulk != M) {                                          // bulk launch + one RAGGED stage for the last M % 32 rows
         if (m_bulk) {
-            const int rc = hwgat_linear_tn_bf16(A, B, dW, db, m_bulk, N, K, pro_seed, pro_p, mean, rstd, gamma, beta, stream);
+            const int rc = hwgat_linear_tn_bf16(A, B, dW, db, m_bulk, N, K, pro_seed, pro_p, mean, rstd, gamma, beta, seed_base, stream);
             if (rc) return rc;
         }
         const int64_t rows_t = M - m_bulk;
         TnArgsB t{(const bf16_t*)A + m_bulk * N, (const bf16_t*)B + m_bulk * K, dW, db, mean ? mean + m_bulk : nullptr,
                   mean ? rstd + m_bulk : nullptr, gamma, beta, rows_t, N, K, 1, TMB, pro_seed, pro_p, m_bulk};
+        t.seed_base = seed_base;
         const int grid_t = 8 * (N / 128) * (K / 128);
         hipStream_t stt = (hipStream_t)stream;
         if (pro_p > 0.f) {
@@ -681,6 +686,7 @@ extern "C" int hwgat_linear_tn_bf16(const void* A, const void* B, float* dW, flo
     const int t256 = (N / 256) * (K / 256);
     if (!tn_old && N % 256 == 0 && K % 256 == 0 && M % 32 == 0 && 256 % t256 == 0 && !(pro_p > 0.f && mean)) {
         TnArgsB a{(const bf16_t*)A, (const bf16_t*)B, dW, db, mean, rstd, gamma, beta, M, N, K, 1, M, pro_seed, pro_p, 0};
+        a.seed_base = seed_base;
         return hwgat_launch_tn256_bf16(a, (hipStream_t)stream);
     }
     const int n_tiles = (N / 128) * (K / 128);
@@ -702,6 +708,7 @@ extern "C" int hwgat_linear_tn_bf16(const void* A, const void* B, float* dW, flo
     const int n_split = (int)((M + rows - 1) / rows);
     TnArgsB a{(const bf16_t*)A, (const bf16_t*)B, dW, db, mean, rstd, gamma, beta, M, N, K, n_split, rows,
               pro_seed, pro_p, 0};
+    a.seed_base = seed_base;
     const int grid = ((n_split + 7) / 8) * 8 * n_tiles;
     hipStream_t st = (hipStream_t)stream;
     if (pro_p > 0.f) {

@@ -40,6 +40,7 @@ __device__ __forceinline__ void pin() {
 // STAT: 0 = plain epilogue, 1 = + row statistics, 2 = + row statistics and the merged store (separate instantiations)
 template <int PRO, int EPI, int STAT = 0>
 __global__ __launch_bounds__(256, 1) void gemm_nt256_bf16_k(NtArgsB p) {
+    HWGAT_RESOLVE_SEEDS2(p);
     __shared__ __attribute__((aligned(16))) unsigned char smb[2 * BUFB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane & 31, hh = lane >> 5;

@@ -56,6 +56,7 @@ __device__ __forceinline__ void wg_barrier() {          // raw: no implicit vmcn
 // 4 = no DMA and no fragment reads -- what each part of the schedule costs (tools/nt8w_lab.py).
 template <int EPI, int STAT, int DBG = 0>
 __global__ __launch_bounds__(512, 2) void gemm_nt8w_bf16_k(NtArgsB p) {
+    HWGAT_RESOLVE_SEEDS2(p);
     __shared__ __attribute__((aligned(16))) unsigned char smb[SMEM];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -46,6 +46,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const lds_bf16* a0) {
 
 template <int PRO, bool BLN, int NSET>     // NSET: 2 or 3
 __global__ __launch_bounds__(256, 1) void gemm_tn256_bf16_k(TnArgsB p) {
+    HWGAT_RESOLVE_SEED1(p);
     __shared__ __attribute__((aligned(16))) bf16_t sm[NST * STG];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane & 31, hh = lane >> 5;

@@ -15,6 +15,7 @@ struct NtArgs {
     // goes to row (b, f/2, k), columns (f & 1) N .. of a (B, F/2, K, 2N) tensor; statistics are then per MERGED row.
     float* stat_sum; float* stat_sq;
     int mg_F, mg_K;
+    const uint32_t* seed_base;   // device word added to the site seeds at kernel entry (NULL = 0), see common.h
 };
 
 // destination of output row m under the merged store: row (b, f, k) -> merged row (b, f/2, k), column offset (f & 1) N.
@@ -50,6 +51,7 @@ struct TnArgs {
     int n_split; int64_t rows_per_split;
     uint32_t pro_seed; float pro_p;
     int64_t row0;          // see NtArgs
+    const uint32_t* seed_base;   // device word added to the site seeds at kernel entry (NULL = 0), see common.h
 };
 
 

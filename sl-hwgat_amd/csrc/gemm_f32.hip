@@ -54,6 +54,7 @@ using NtK16 = TileCfg<2, 2, 2, 2, 16, 3>;                      // 41 KB LDS -> 3
 // (STAT: 0 = plain, 1 = + row statistics, 2 = + row statistics and the merged store)
 template <int PRO, int EPI, typename C, bool RAGGED = false, int STAT = 0>
 __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_nt_k(NtArgs p) {
+    HWGAT_RESOLVE_SEEDS2(p);
     constexpr int BM = C::BM, BN = C::BN, TMW = C::TMW, TNW = C::TNW, PA = C::PA, PW = C::PW, RPP = C::RPP;
     constexpr int BK = C::BK, LDT = C::LDT;
     __shared__ __attribute__((aligned(16))) float sm[2 * (BM + BN) * LDT];    // [buf][A rows | W rows][36]
@@ -334,6 +335,7 @@ using TnK16 = TileCfg<2, 2, 2, 2, 16, 3>;                      // 32 KB LDS -> 3
 // RAGGED: launch over the last M % 32 rows (see gemm_nt_k): one partial stage, rows >= M count as zero.
 template <int PRO, bool BLN, typename C, bool MF16 = false, bool RAGGED = false>
 __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_tn_k(TnArgs p) {
+    HWGAT_RESOLVE_SEED1(p);
     constexpr int TM = C::BK;
     constexpr int BT = C::BM;                                  // == C::BN
     constexpr int LDR = MF16 ? BT + 16 : BT;                   // LDS row stride: +16 keeps the 4 rows of a 16x16x4 operand on distinct banks
@@ -595,7 +597,7 @@ extern "C" int hwgat_linear_nt_f32_ex(const float* A, const float* W, const floa
                                       const float* gamma, const float* beta, uint32_t pro_seed, float pro_p,
                                       int epi, const float* res, float* C2, const float* aux, uint32_t epi_seed,
                                       float epi_p, float* stat_sum, float* stat_sq, int merge_F, int merge_K,
-                                      void* stream) {
+                                      const uint32_t* seed_base, void* stream) {
     if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) return HWGAT_EINVAL;
     if (N % 128 || K % 32 || ((M + 127) / 128) * (int64_t)(N / 128) > 0x7fffffff) return HWGAT_ESHAPE;   // any M
     if ((pro == PRO_LN || pro == PRO_LN_FOLD) && (!mean || !rstd || !gamma || !beta)) return HWGAT_EINVAL;
@@ -615,6 +617,7 @@ extern "C" int hwgat_linear_nt_f32_ex(const float* A, const float* W, const floa
     }
     if (pro == PRO_DROP && pro_p == 0.f) pro = PRO_NONE;          // eval mode: no mask to hash
     NtArgs a{A, W, bias, C, C2, res, aux, mean, rstd, gamma, beta, M, N, K, pro_seed, epi_seed, pro_p, epi_p, 0, stat_sum, stat_sq, merge_K > 0 ? merge_F : 0, merge_K > 0 ? merge_K : 0};
+    a.seed_base = seed_base;
     hipStream_t st = (hipStream_t)stream;
     // a token count that is not a multiple of the 128-row tile: bulk launch over the aligned rows with the
     // unmodified kernels, then one small RAGGED launch for the last M % 128 rows
@@ -622,7 +625,7 @@ extern "C" int hwgat_linear_nt_f32_ex(const float* A, const float* W, const floa
     if (m_bulk != M) {
         if (m_bulk) {
             const int rc = hwgat_linear_nt_f32(A, W, bias, C, m_bulk, N, K, pro, mean, rstd, gamma, beta, pro_seed, pro_p,
-                                               epi, res, C2, aux, epi_seed, epi_p, stream);
+                                               epi, res, C2, aux, epi_seed, epi_p, seed_base, stream);
             if (rc) return rc;
         }
         const NtArgs t = nt_rows(a, m_bulk, M - m_bulk);
@@ -688,9 +691,9 @@ extern "C" int hwgat_linear_nt_f32(const float* A, const float* W, const float* 
                                    int N, int K, int pro, const float* mean, const float* rstd,
                                    const float* gamma, const float* beta, uint32_t pro_seed, float pro_p,
                                    int epi, const float* res, float* C2, const float* aux, uint32_t epi_seed,
-                                   float epi_p, void* stream) {
+                                   float epi_p, const uint32_t* seed_base, void* stream) {
     return hwgat_linear_nt_f32_ex(A, W, bias, C, M, N, K, pro, mean, rstd, gamma, beta, pro_seed, pro_p, epi, res, C2, aux,
-                                  epi_seed, epi_p, nullptr, nullptr, 0, 0, stream);
+                                  epi_seed, epi_p, nullptr, nullptr, 0, 0, seed_base, stream);
 }
 
 static bool tn256_takes(int64_t M, int N, int K, float pro_p, const float* mean) {
@@ -706,30 +709,33 @@ extern "C" int64_t hwgat_linear_tn_f32_ws_bytes(int64_t M, int N, int K) {
 extern "C" int hwgat_linear_tn_f32_ws(const float* A, const float* B, float* dW, float* db, int64_t M, int N,
                                       int K, uint32_t pro_seed, float pro_p, const float* mean,
                                       const float* rstd, const float* gamma, const float* beta, float* ws,
-                                      int64_t ws_bytes, void* stream) {
+                                      int64_t ws_bytes, const uint32_t* seed_base, void* stream) {
     if (!A || !B || !dW || M <= 0 || N <= 0 || K <= 0) return HWGAT_EINVAL;
     if (mean && (!rstd || !gamma || !beta)) return HWGAT_EINVAL;
     if (pro_p < 0.f || pro_p >= 1.f) return HWGAT_EINVAL;
     if (ws && ws_bytes > 0 && N % 128 == 0 && K % 128 == 0 && tn256_takes(M, N, K, pro_p, mean)) {
         TnArgs a{A, B, dW, db, mean, rstd, gamma, beta, M, N, K, 0, 0, pro_seed, pro_p, 0};
+        a.seed_base = seed_base;
         return hwgat_launch_tn256(a, (hipStream_t)stream, ws, ws_bytes / 4);
     }
-    return hwgat_linear_tn_f32(A, B, dW, db, M, N, K, pro_seed, pro_p, mean, rstd, gamma, beta, stream);
+    return hwgat_linear_tn_f32(A, B, dW, db, M, N, K, pro_seed, pro_p, mean, rstd, gamma, beta, seed_base, stream);
 }
 
 extern "C" int hwgat_linear_tn_f32(const float* A, const float* B, float* dW, float* db, int64_t M, int N,
                                    int K, uint32_t pro_seed, float pro_p, const float* mean,
-                                   const float* rstd, const float* gamma, const float* beta, void* stream) {
+                                   const float* rstd, const float* gamma, const float* beta,
+                                   const uint32_t* seed_base, void* stream) {
     if (!A || !B || !dW || M <= 0 || N <= 0 || K <= 0) return HWGAT_EINVAL;
     if (mean && (!rstd || !gamma || !beta)) return HWGAT_EINVAL;
     if (N % 128 || K % 128) return HWGAT_ESHAPE;                 // any M
     if (pro_p < 0.f || pro_p >= 1.f) return HWGAT_EINVAL;
     TnArgs a{A, B, dW, db, mean, rstd, gamma, beta, M, N, K, 0, 0, pro_seed, pro_p, 0};
+    a.seed_base = seed_base;
     hipStream_t st = (hipStream_t)stream;
     const int64_t m_bulk = M / 32 * 32;                         // rows per LDS stage; the tail gets a RAGGED launch
     if (m_bulk != M) {
         if (m_bulk) {
-            const int rc = hwgat_linear_tn_f32(A, B, dW, db, m_bulk, N, K, pro_seed, pro_p, mean, rstd, gamma, beta, stream);
+            const int rc = hwgat_linear_tn_f32(A, B, dW, db, m_bulk, N, K, pro_seed, pro_p, mean, rstd, gamma, beta, seed_base, stream);
             if (rc) return rc;
         }
         const TnArgs t = tn_rows(a, m_bulk, M - m_bulk);
@@ -761,15 +767,16 @@ extern "C" int hwgat_transpose_f32(const float* in, float* out, int R, int C, vo
 }
 
 // expose the dropout hash so host tests can reproduce masks bit for bit
-__global__ void drop_mask_k(float* out, int64_t n, uint32_t seed, float p) {
+__global__ void drop_mask_k(float* out, int64_t n, uint32_t seed, float p, const uint32_t* seed_base) {
+    seed += seed_base_of(seed_base);
     const uint32_t th = drop_thresh(p);
     const float sc = 1.0f / (1.0f - p);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
         out[i] = drop_keep(seed, (uint64_t)i, th, sc);
 }
-extern "C" int hwgat_dropout_mask_f32(float* out, int64_t n, uint32_t seed, float p, void* stream) {
+extern "C" int hwgat_dropout_mask_f32(float* out, int64_t n, uint32_t seed, float p, const uint32_t* seed_base, void* stream) {
     if (!out || n <= 0 || p < 0.f || p >= 1.f) return HWGAT_EINVAL;
     const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-    drop_mask_k<<<grid, 256, 0, (hipStream_t)stream>>>(out, n, seed, p);
+    drop_mask_k<<<grid, 256, 0, (hipStream_t)stream>>>(out, n, seed, p, seed_base);
     HWGAT_LAUNCH_CHECK();
 }

@@ -57,6 +57,7 @@ __device__ __forceinline__ void pin() {
 //  3 = X_LNFOLD, the row-affine epilogue of a folded LayerNorm -- fused_ops.h)
 template <int PRO, int EPI, int STAT = 0>
 __global__ __launch_bounds__(256, 1) void gemm_nt256_k(NtArgs p) {
+    HWGAT_RESOLVE_SEEDS2(p);
     __shared__ __attribute__((aligned(16))) float sm[2 * BUF];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane & 31, hh = lane >> 5;

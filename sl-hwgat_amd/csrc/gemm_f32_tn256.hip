@@ -43,6 +43,7 @@ __device__ __forceinline__ void il8() {
 //   ws[(split * n_tiles + tile) * 65536 + (((wave * 16 + i * 4 + jj) * 4 + q) * 64 + lane) * 4 + e] = acc[i][jj][4 q + e]
 template <int PRO, bool BLN, bool SLAB = false>
 __global__ __launch_bounds__(256, 1) void gemm_tn256_k(TnArgs p, float* __restrict__ ws = nullptr) {
+    HWGAT_RESOLVE_SEED1(p);
     __shared__ __attribute__((aligned(16))) float sm[NST * STG];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lq = lane & 31, hh = lane >> 5;

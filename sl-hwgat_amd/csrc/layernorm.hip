@@ -103,8 +103,9 @@ __global__ __launch_bounds__(256) void ln_bwd_k(const T* __restrict__ dy, const 
                                                 T* __restrict__ dx, float* __restrict__ dgamma,
                                                 float* __restrict__ dbeta, int64_t N, T* __restrict__ dxm,
                                                 uint32_t mseed, float mp, const float* __restrict__ beta = nullptr,
-                                                T* __restrict__ xn = nullptr) {
+                                                T* __restrict__ xn = nullptr, const uint32_t* __restrict__ sbase = nullptr) {
     using M = RowMap<D>;
+    if constexpr (MASK) mseed += seed_base_of(sbase);
     __shared__ float red[2][4][D];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int sub = lane % M::LPR, rsub = lane / M::LPR;
@@ -268,8 +269,9 @@ __global__ __launch_bounds__(256) void lnpool_bwd_k(const float* __restrict__ g,
                                                     const float* __restrict__ mean_i,
                                                     const float* __restrict__ rstd_i, T* __restrict__ dx,
                                                     int n_tok, int chunks, T* __restrict__ dxm, uint32_t mseed,
-                                                    float mp) {
+                                                    float mp, const uint32_t* __restrict__ sbase) {
     using M = RowMap<D>;
+    mseed += seed_base_of(sbase);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int sub = lane % M::LPR, rsub = lane / M::LPR;
     const int b = blockIdx.x / chunks, ch = blockIdx.x % chunks;
@@ -334,11 +336,12 @@ int ln_fwd_t(const void* x, const float* gm, const float* bt, void* y, float* me
 template <typename T, bool RES, bool MASK = false, bool XN = false>
 int ln_bwd_t(const void* dy, const void* x, const float* mean, const float* rstd, const float* gm,
              const void* dres, void* dx, float* dg, float* db, int64_t N, int d, hipStream_t st,
-             void* dxm = nullptr, uint32_t mseed = 0, float mp = 0.f, const float* bt = nullptr, void* xn = nullptr) {
+             void* dxm = nullptr, uint32_t mseed = 0, float mp = 0.f, const float* bt = nullptr, void* xn = nullptr,
+             const uint32_t* sbase = nullptr) {
 #define GO(D)                                                                                                        \
     ln_bwd_k<T, D, RES, MASK, XN><<<(ln_grid(N, RowMap<D>::RPW) < 1024 ? ln_grid(N, RowMap<D>::RPW) : 1024), 256, 0, \
                                     st>>>((const T*)dy, (const T*)x, mean, rstd, gm, (const T*)dres, (T*)dx, dg, db, \
-                                          N, (T*)dxm, mseed, mp, bt, (T*)xn)
+                                          N, (T*)dxm, mseed, mp, bt, (T*)xn, sbase)
     switch (d) {
         case 128: GO(128); break;
         case 256: GO(256); break;
@@ -439,27 +442,28 @@ extern "C" int hwgat_ln_bwd(const void* dy, const void* x, const float* mean, co
 extern "C" int hwgat_ln_bwd_masked(const void* dy, const void* x, const float* mean, const float* rstd,
                                    const float* gamma, const void* dres, void* dx, float* dgamma, float* dbeta,
                                    int64_t N, int d, int dtype, void* dx_masked, uint32_t mask_seed, float mask_p,
-                                   void* stream) {
+                                   const uint32_t* seed_base, void* stream) {
     if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || !dres || !dx_masked || N <= 0) return HWGAT_EINVAL;
     if (mask_p <= 0.f || mask_p >= 1.f) return HWGAT_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == HWGAT_F32)
-        return ln_bwd_t<float, true, true>(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, N, d, st, dx_masked, mask_seed, mask_p);
+        return ln_bwd_t<float, true, true>(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, N, d, st, dx_masked, mask_seed, mask_p, nullptr, nullptr, seed_base);
     if (dtype == HWGAT_BF16)
-        return ln_bwd_t<bf16_t, true, true>(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, N, d, st, dx_masked, mask_seed, mask_p);
+        return ln_bwd_t<bf16_t, true, true>(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, N, d, st, dx_masked, mask_seed, mask_p, nullptr, nullptr, seed_base);
     return HWGAT_EDTYPE;
 }
 
 // hwgat_ln_bwd (+ optional masked copy) that ALSO writes xn = LN(x) (see ln_bwd_k<.., XN>); dres required
 extern "C" int hwgat_ln_bwd_xn(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                                const float* beta, const void* dres, void* dx, float* dgamma, float* dbeta, int64_t N, int d,
-                               int dtype, void* dx_masked, uint32_t mask_seed, float mask_p, void* xn, void* stream) {
+                               int dtype, void* dx_masked, uint32_t mask_seed, float mask_p, void* xn,
+                               const uint32_t* seed_base, void* stream) {
     if (!dy || !x || !mean || !rstd || !gamma || !beta || !dx || !dgamma || !dbeta || !dres || !xn || N <= 0) return HWGAT_EINVAL;
     if (dx_masked && (mask_p <= 0.f || mask_p >= 1.f)) return HWGAT_EINVAL;
     hipStream_t st = (hipStream_t)stream;
 #define GO(T)                                                                                                             \
     return dx_masked ? ln_bwd_t<T, true, true, true>(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, N, d, st, dx_masked, \
-                                                     mask_seed, mask_p, beta, xn)                                         \
+                                                     mask_seed, mask_p, beta, xn, seed_base)                              \
                      : ln_bwd_t<T, true, false, true>(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, N, d, st, nullptr, \
                                                       0, 0.f, beta, xn)
     if (dtype == HWGAT_F32) { GO(float); }
@@ -499,21 +503,21 @@ extern "C" int hwgat_lnpool_fwd(const void* x, float* xhat_sum, float* mean, flo
 
 extern "C" int hwgat_lnpool_bwd_masked(const float* g, const void* x, const float* mean, const float* rstd, void* dx,
                                        int B, int n_tok, int d, int dtype, void* dx_masked, uint32_t mask_seed,
-                                       float mask_p, void* stream);
+                                       float mask_p, const uint32_t* seed_base, void* stream);
 
 extern "C" int hwgat_lnpool_bwd(const float* g, const void* x, const float* mean, const float* rstd, void* dx,
                                 int B, int n_tok, int d, int dtype, void* stream) {
-    return hwgat_lnpool_bwd_masked(g, x, mean, rstd, dx, B, n_tok, d, dtype, nullptr, 0, 0.f, stream);
+    return hwgat_lnpool_bwd_masked(g, x, mean, rstd, dx, B, n_tok, d, dtype, nullptr, 0, 0.f, nullptr, stream);
 }
 
 extern "C" int hwgat_lnpool_bwd_masked(const float* g, const void* x, const float* mean, const float* rstd, void* dx,
                                        int B, int n_tok, int d, int dtype, void* dxm, uint32_t mseed, float mp,
-                                       void* stream) {
+                                       const uint32_t* seed_base, void* stream) {
     if (!g || !x || !mean || !rstd || !dx || B <= 0 || n_tok <= 0) return HWGAT_EINVAL;
     if (dxm && (mp <= 0.f || mp >= 1.f)) return HWGAT_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int ch = pool_chunks(B, n_tok);
-#define GO(T, D) lnpool_bwd_k<T, D><<<B * ch, 256, 0, st>>>(g, (const T*)x, mean, rstd, (T*)dx, n_tok, ch, (T*)dxm, mseed, mp)
+#define GO(T, D) lnpool_bwd_k<T, D><<<B * ch, 256, 0, st>>>(g, (const T*)x, mean, rstd, (T*)dx, n_tok, ch, (T*)dxm, mseed, mp, seed_base)
     if (dtype == HWGAT_F32) { SW(float) }
     else if (dtype == HWGAT_BF16) { SW(bf16_t) }
     else return HWGAT_EDTYPE;

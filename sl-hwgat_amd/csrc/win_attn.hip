@@ -109,6 +109,7 @@ __device__ __forceinline__ uint32_t masked_softmax(float (&s)[16], float (&p)[16
 struct AttnDrop {
     uint32_t seed;
     float p;                    // 0: no attention dropout
+    const uint32_t* base;       // device word added to `seed` at kernel entry (NULL = 0), see common.h
 };
 __device__ __forceinline__ void attn_keep(float (&k)[16], const AttnDrop& ad, int u, int lq, int hh) {
     const uint64_t base = ((uint64_t)u * 32 + lq) * 32 + 4 * hh;
@@ -127,6 +128,7 @@ __global__ __launch_bounds__(256, 2) void win_attn_fwd_k(const T* __restrict__ q
                                                          const uint32_t* __restrict__ maskbits,
                                                          const float* __restrict__ thr_p, WinGeom g,
                                                          int n_units, AttnDrop ad) {
+    if constexpr (ADROP) ad.seed += seed_base_of(ad.base);
     using TL = tile_of<T>;             // fp32: fp32 tiles and MFMAs; bf16: raw bf16 tiles, v_mfma_f32_32x32x16_bf16 (attn_common.h)
     using E = typename TL::E;
     constexpr bool B16 = sizeof(T) == 2;
@@ -250,6 +252,7 @@ __global__ __launch_bounds__(WAVES * 64, (sizeof(T) == 2 && HD <= 64) ? 2 : 1) v
                                                                 const uint32_t* __restrict__ maskbits,
                                                                 const float* __restrict__ thr_p,
                                                                 WinGeom g, int n_units, AttnDrop ad) {
+    if constexpr (ADROP) ad.seed += seed_base_of(ad.base);
     using TL = tile_of<T>;                                   // see win_attn_fwd_k
     using E = typename TL::E;
     constexpr int LDW = HD + TL::PAD;
@@ -390,6 +393,7 @@ __global__ __launch_bounds__(128, sizeof(T) == 2 ? 3 : 2) void win_attn_bwd_spli
                                                                const uint32_t* __restrict__ maskbits,
                                                                const float* __restrict__ thr_p, WinGeom g,
                                                                int n_units, AttnDrop ad) {
+    if constexpr (ADROP) ad.seed += seed_base_of(ad.base);
     using TL = tile_of<T>;                                     // see win_attn_fwd_k
     using E = typename TL::E;
     constexpr int HD = 128, HW = 64, LDW = HW + TL::PAD, NT = HW / 32;
@@ -658,7 +662,7 @@ int launch_bwd(const void* qkv, const void* dO, void* dqkv, const uint32_t* mb, 
 
 // attention dropout only exists in train mode (thr given); p in [0, 1)
 bool drop_ok(const float* thr, float p) { return p >= 0.f && p < 1.f && (p == 0.f || thr); }
-AttnDrop make_drop(uint32_t seed, float p) { return AttnDrop{seed, p < 0.5f / 65536.0f ? 0.f : p}; }   // p is quantised to 1/65536 (fused_ops.h)
+AttnDrop make_drop(uint32_t seed, float p, const uint32_t* base) { return AttnDrop{seed, p < 0.5f / 65536.0f ? 0.f : p, base}; }   // p is quantised to 1/65536 (fused_ops.h)
 
 }  // namespace
 
@@ -682,14 +686,14 @@ extern "C" int hwgat_debug_mfma_peak(float* out, int blocks, int iters, int n_ac
 
 extern "C" int hwgat_win_attn_fwd_drop(const void* qkv, void* o, const uint32_t* maskbits, const float* thr,
                                        int B, int F, int nW, int nH, int hd, int shifted, int dtype,
-                                       uint32_t drop_seed, float drop_p, void* stream) {
+                                       uint32_t drop_seed, float drop_p, const uint32_t* seed_base, void* stream) {
     if (!qkv || !o || !maskbits || !drop_ok(thr, drop_p)) return HWGAT_EINVAL;
     if (!geom_ok(B, F, nW, nH, hd)) return HWGAT_ESHAPE;
     WinGeom g{F, nW * 16, nW, nH, F / 2, nH * hd, shifted ? 1 : 0};
     const int64_t units = (int64_t)B * g.f * nW * nH;
     if (units > 0x7fffffff) return HWGAT_ESHAPE;
     hipStream_t st = (hipStream_t)stream;
-    const AttnDrop ad = make_drop(drop_seed, drop_p);
+    const AttnDrop ad = make_drop(drop_seed, drop_p, seed_base);
 #define FWD(T)                                                                                      \
     switch (hd) {                                                                                   \
         case 32: return launch_fwd<T, 32>(qkv, o, maskbits, thr, g, (int)units, ad, st);            \
@@ -705,19 +709,19 @@ extern "C" int hwgat_win_attn_fwd_drop(const void* qkv, void* o, const uint32_t*
 extern "C" int hwgat_win_attn_fwd(const void* qkv, void* o, const uint32_t* maskbits, const float* thr,
                                   int B, int F, int nW, int nH, int hd, int shifted, int dtype,
                                   void* stream) {
-    return hwgat_win_attn_fwd_drop(qkv, o, maskbits, thr, B, F, nW, nH, hd, shifted, dtype, 0u, 0.f, stream);
+    return hwgat_win_attn_fwd_drop(qkv, o, maskbits, thr, B, F, nW, nH, hd, shifted, dtype, 0u, 0.f, nullptr, stream);
 }
 
 extern "C" int hwgat_win_attn_bwd_drop(const void* qkv, const void* dO, void* dqkv, const uint32_t* maskbits,
                                        const float* thr, int B, int F, int nW, int nH, int hd, int shifted,
-                                       int dtype, uint32_t drop_seed, float drop_p, void* stream) {
+                                       int dtype, uint32_t drop_seed, float drop_p, const uint32_t* seed_base, void* stream) {
     if (!qkv || !dO || !dqkv || !maskbits || !drop_ok(thr, drop_p)) return HWGAT_EINVAL;
     if (!geom_ok(B, F, nW, nH, hd)) return HWGAT_ESHAPE;
     WinGeom g{F, nW * 16, nW, nH, F / 2, nH * hd, shifted ? 1 : 0};
     const int64_t units = (int64_t)B * g.f * nW * nH;
     if (units > 0x7fffffff) return HWGAT_ESHAPE;
     hipStream_t st = (hipStream_t)stream;
-    const AttnDrop ad = make_drop(drop_seed, drop_p);
+    const AttnDrop ad = make_drop(drop_seed, drop_p, seed_base);
 #define BWD(T)                                                                                            \
     switch (hd) {                                                                                         \
         case 32: return launch_bwd<T, 32>(qkv, dO, dqkv, maskbits, thr, g, (int)units, ad, st);           \
@@ -733,5 +737,5 @@ extern "C" int hwgat_win_attn_bwd_drop(const void* qkv, const void* dO, void* dq
 extern "C" int hwgat_win_attn_bwd(const void* qkv, const void* dO, void* dqkv, const uint32_t* maskbits,
                                   const float* thr, int B, int F, int nW, int nH, int hd, int shifted,
                                   int dtype, void* stream) {
-    return hwgat_win_attn_bwd_drop(qkv, dO, dqkv, maskbits, thr, B, F, nW, nH, hd, shifted, dtype, 0u, 0.f, stream);
+    return hwgat_win_attn_bwd_drop(qkv, dO, dqkv, maskbits, thr, B, F, nW, nH, hd, shifted, dtype, 0u, 0.f, nullptr, stream);
 }

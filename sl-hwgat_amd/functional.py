@@ -127,13 +127,15 @@ def band_mask_rows(adj: torch.Tensor, frames: int) -> torch.Tensor:
 
 
 # ---------------------------------------------------------------- embedding
-def embed(x, idx, bmat, pe, K, out_dtype=torch.float32, drop_p=0.0, seed=0):
-    """gather + Fourier features + PE (+ dropout) (no gradient: B is frozen, PE a buffer)."""
+def embed(x, idx, bmat, pe, K, out_dtype=torch.float32, drop_p=0.0, seed=0, seed_base=None):
+    """gather + Fourier features + PE (+ dropout) (no gradient: B is frozen, PE a buffer).
+    `seed_base` (here and in every function below that takes a dropout seed): None, or a 1-element device tensor whose
+    32-bit word the kernel adds to the site seed when it RUNS (include/hwgat_hip.h, "dropout seeds")."""
     B, T, J, C = x.shape
     d0 = bmat.shape[0] * 2
     out = torch.empty(B, T, K, d0, device=x.device, dtype=out_dtype)
     call("hwgat_embed_fwd", ptr(x), ptr(idx), ptr(bmat), ptr(pe), ptr(out),
-         B, T, J, K, C, d0, dtype_code(out), seed & 0xFFFFFFFF, float(drop_p), stream())
+         B, T, J, K, C, d0, dtype_code(out), seed & 0xFFFFFFFF, float(drop_p), ptr(seed_base), stream())
     return out
 
 
@@ -197,17 +199,17 @@ def _attn_drop(kind, thr, drop):
         raise NotImplementedError("attention dropout exists for the HWGATE window attention only")
     if thr is None:
         raise ValueError("attention dropout is a train-mode operation: it needs the train-mode threshold tensor")
-    return int(drop[0]) & 0xFFFFFFFF, float(drop[1])
+    return int(drop[0]) & 0xFFFFFFFF, float(drop[1]), (drop[2] if len(drop) > 2 else None)
 
 
 def attn_fwd(kind, qkv, o, bits, thr, n_heads, shifted, drop=None):
     """launch the attention forward of a model family: 'win' = HWGATE part windows, 'blk' = HGATE blocks, 'band' = WGATE.
-    `drop` = (seed, p): attention dropout ('win', train mode only)"""
+    `drop` = (seed, p) or (seed, p, seed_base): attention dropout ('win', train mode only)"""
     B, F, K, d = o.shape
     drop = _attn_drop(kind, thr, drop)
     if kind == "win" and drop is not None:
         call("hwgat_win_attn_fwd_drop", ptr(qkv), ptr(o), ptr(bits), ptr(thr), B, F, K // 16, n_heads, d // n_heads,
-             int(shifted), dtype_code(qkv), drop[0], drop[1], stream())
+             int(shifted), dtype_code(qkv), drop[0], drop[1], ptr(drop[2]), stream())
     elif kind == "win":
         call("hwgat_win_attn_fwd", ptr(qkv), ptr(o), ptr(bits), ptr(thr), B, F, K // 16, n_heads, d // n_heads,
              int(shifted), dtype_code(qkv), stream())
@@ -228,7 +230,7 @@ def attn_bwd(kind, qkv, do, dqkv, bits, thr, n_heads, shifted, drop=None):
     drop = _attn_drop(kind, thr, drop)
     if kind == "win" and drop is not None:
         call("hwgat_win_attn_bwd_drop", ptr(qkv), ptr(do), ptr(dqkv), ptr(bits), ptr(thr), B, F, K // 16, n_heads,
-             d // n_heads, int(shifted), dtype_code(qkv), drop[0], drop[1], stream())
+             d // n_heads, int(shifted), dtype_code(qkv), drop[0], drop[1], ptr(drop[2]), stream())
     elif kind == "win":
         call("hwgat_win_attn_bwd", ptr(qkv), ptr(do), ptr(dqkv), ptr(bits), ptr(thr), B, F, K // 16, n_heads,
              d // n_heads, int(shifted), dtype_code(qkv), stream())
@@ -324,10 +326,11 @@ def temporal_merge(x):
 # ---------------------------------------------------------------- LN + pool
 class _LnPool(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, xc=None, up=None, book=None, deterministic=False):
+    def forward(ctx, x, gamma, beta, xc=None, up=None, book=None, deterministic=False, seed_base=None):
         # xc / up / book: carrier of the masked gradient for the block that produced x (block.fused_block)
         ctx.up = up if (xc is not None and up is not None and up[1] > 0.0 and book is not None) else None
         ctx.book = book
+        ctx.seed_base = seed_base
         B, d = x.shape[0], x.shape[-1]
         n_tok = x.numel() // (B * d)
         mean = torch.empty(B * n_tok, device=x.device, dtype=torch.float32)
@@ -354,20 +357,21 @@ class _LnPool(torch.autograd.Function):
         dx = torch.empty_like(x)
         dxm = torch.empty_like(x) if ctx.up is not None else None
         call("hwgat_lnpool_bwd_masked", ptr(g), ptr(x), ptr(mean), ptr(rstd), ptr(dx), B, n_tok, d,
-             dtype_code(x), ptr(dxm), (ctx.up[0] if ctx.up else 0) & 0xFFFFFFFF, float(ctx.up[1]) if ctx.up else 0.0, stream())
+             dtype_code(x), ptr(dxm), (ctx.up[0] if ctx.up else 0) & 0xFFFFFFFF, float(ctx.up[1]) if ctx.up else 0.0,
+             ptr(ctx.seed_base), stream())
         if dxm is not None:
             ctx.book.register(dx, dxm)
-        return dx, (dfeat * hat_mean).sum(0), dfeat.sum(0), dxm, None, None, None
+        return dx, (dfeat * hat_mean).sum(0), dfeat.sum(0), dxm, None, None, None, None
 
 
-def ln_mean_pool(x, gamma, beta, carrier=None, up=None, book=None, deterministic=False):
+def ln_mean_pool(x, gamma, beta, carrier=None, up=None, book=None, deterministic=False, seed_base=None):
     """final LayerNorm + mean over all tokens -> (B, d) fp32.  carrier / up / book: see block.fused_block (the last
     block's fc2-dropout mask is applied to its incoming gradient here, once).  `deterministic`: fixed summation order
     (two launches, no atomics), what eval() uses so that two forwards are bit-identical like the reference's."""
     xcont = x.contiguous()
     if carrier is not None and (xcont is not x or carrier.shape != x.shape or book is None):
         carrier = None
-    return _LnPool.apply(xcont, gamma, beta, carrier, up, book, bool(deterministic))
+    return _LnPool.apply(xcont, gamma, beta, carrier, up, book, bool(deterministic), seed_base)
 
 
 # ---------------------------------------------------------------- fp32 MFMA linears
@@ -513,6 +517,7 @@ class HandOver:
         self.deterministic = bool(deterministic)
         self.book = CarryBook()
         self.prep = None            # WeightPrep of this call (per_block[k] = the derived weight copies of block k)
+        self.seed_base = None       # 1-element device tensor: the base seed of this call's dropout masks (or None)
 
 
 EPI_BIAS, EPI_BIAS_DROP_RES, EPI_BIAS_GELU_DROP, EPI_GELU_BWD, EPI_NONE, EPI_BIAS_GELU_DROP_G, EPI_MUL_AUX = 0, 1, 2, 3, 4, 5, 6
@@ -524,7 +529,7 @@ def can_fuse_row_stats(x):
 
 
 def linear_nt(A, W, bias=None, *, pro=PRO_NONE, ln=None, pro_seed=0, pro_p=0.0, epi=EPI_BIAS,
-              res=None, aux=None, epi_seed=0, epi_p=0.0, out=None, stats=False, merge=None):
+              res=None, aux=None, epi_seed=0, epi_p=0.0, out=None, stats=False, merge=None, seed_base=None):
     """C[M,N] = pro(A)[M,K] . W[N,K]^T with fused epilogue (see include/hwgat_hip.h).
     Returns C, or (C, C2) for EPI_BIAS_GELU_DROP (C2 = pre-activation) / EPI_BIAS_GELU_DROP_G (C2 = gelu' * mask).
     EPI_BIAS_DROP_RES: `stats=True` also returns (mean, rstd) of the OUTPUT rows, produced by the epilogue
@@ -549,7 +554,7 @@ def linear_nt(A, W, bias=None, *, pro=PRO_NONE, ln=None, pro_seed=0, pro_p=0.0, 
         call("hwgat_linear_nt_f32_ex" if A.dtype == torch.float32 else "hwgat_linear_nt_bf16_ex",
              ptr(A), ptr(W), ptr(bias), ptr(C), M, N, K, pro, None, None, None, None,
              pro_seed & 0xFFFFFFFF, float(pro_p), epi, ptr(res), None, None, epi_seed & 0xFFFFFFFF, float(epi_p),
-             ptr(st[0]), ptr(st[1]), merge[0] if merge else 0, merge[1] if merge else 0, stream())
+             ptr(st[0]), ptr(st[1]), merge[0] if merge else 0, merge[1] if merge else 0, ptr(seed_base), stream())
         call("hwgat_ln_finalize", ptr(st[0]), ptr(st[1]), rows, width, stream())
         return C, st[0], st[1]
     C = out if out is not None else torch.empty(*A.shape[:-1], N, device=A.device, dtype=A.dtype)
@@ -559,7 +564,7 @@ def linear_nt(A, W, bias=None, *, pro=PRO_NONE, ln=None, pro_seed=0, pro_p=0.0, 
         mean, rstd, gamma, beta = ln
     call("hwgat_linear_nt_f32" if A.dtype == torch.float32 else "hwgat_linear_nt_bf16", ptr(A), ptr(W), ptr(bias), ptr(C), M, N, K, pro, ptr(mean), ptr(rstd),
          ptr(gamma), ptr(beta), pro_seed & 0xFFFFFFFF, float(pro_p), epi, ptr(res), ptr(C2), ptr(aux),
-         epi_seed & 0xFFFFFFFF, float(epi_p), stream())
+         epi_seed & 0xFFFFFFFF, float(epi_p), ptr(seed_base), stream())
     return (C, C2) if C2 is not None else C
 
 
@@ -573,7 +578,7 @@ def ln_fold(W, bias, gamma, beta, dtype):
     return Wf, sc[0], sc[1]
 
 
-def linear_nt_ln(A, W, bias, ln, *, epi=EPI_BIAS, epi_seed=0, epi_p=0.0, out=None, folded=None):
+def linear_nt_ln(A, W, bias, ln, *, epi=EPI_BIAS, epi_seed=0, epi_p=0.0, out=None, folded=None, seed_base=None):
     """LN(A) . W^T + bias with the epilogue `epi` (EPI_BIAS or EPI_BIAS_GELU_DROP); W, bias are the fp32 master
     parameters, ln = (mean, rstd, gamma, beta).  Whole-tile token counts take the folded form (no per-element
     normalisation in the GEMM's load path), anything else the normalising loader."""
@@ -581,12 +586,13 @@ def linear_nt_ln(A, W, bias, ln, *, epi=EPI_BIAS, epi_seed=0, epi_p=0.0, out=Non
     M = A.numel() // A.shape[-1]
     if LN_FOLD and M % 128 == 0 and W.dtype == torch.float32 and gamma.dtype == torch.float32:   # hwgat_ln_fold reads fp32 masters
         Wf, s, c = folded if folded is not None else ln_fold(W, bias, gamma, beta, A.dtype)   # `folded`: made by WeightPrep
-        return linear_nt(A, Wf, None, pro=PRO_LN_FOLD, ln=(mean, rstd, s, c), epi=epi, epi_seed=epi_seed, epi_p=epi_p, out=out)
+        return linear_nt(A, Wf, None, pro=PRO_LN_FOLD, ln=(mean, rstd, s, c), epi=epi, epi_seed=epi_seed, epi_p=epi_p, out=out,
+                         seed_base=seed_base)
     Wc = W if W.dtype == A.dtype else W.to(A.dtype)
-    return linear_nt(A, Wc, bias, pro=PRO_LN, ln=ln, epi=epi, epi_seed=epi_seed, epi_p=epi_p, out=out)
+    return linear_nt(A, Wc, bias, pro=PRO_LN, ln=ln, epi=epi, epi_seed=epi_seed, epi_p=epi_p, out=out, seed_base=seed_base)
 
 
-def linear_tn(A, Bm, dW, db=None, *, pro_seed=0, pro_p=0.0, ln=None):
+def linear_tn(A, Bm, dW, db=None, *, pro_seed=0, pro_p=0.0, ln=None, seed_base=None):
     """dW[N,K] += dropmask(A)[M,N]^T . ln(Bm)[M,K]; db[N] += colsum(dropmask(A)).
     ln = (mean, rstd, gamma, beta) normalises Bm on the fly."""
     N, K = dW.shape
@@ -605,10 +611,10 @@ def linear_tn(A, Bm, dW, db=None, *, pro_seed=0, pro_p=0.0, ln=None):
         if need > 0:
             ws = torch.empty(need // 4, device=A.device, dtype=torch.float32)
             call("hwgat_linear_tn_f32_ws", ptr(A), ptr(Bm), ptr(dW), ptr(db), M, N, K, pro_seed & 0xFFFFFFFF, float(pro_p),
-                 ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(ws), need, stream())
+                 ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(ws), need, ptr(seed_base), stream())
             return
     call("hwgat_linear_tn_f32" if A.dtype == torch.float32 else "hwgat_linear_tn_bf16", ptr(A), ptr(Bm), ptr(dW), ptr(db), M, N, K, pro_seed & 0xFFFFFFFF,
-         float(pro_p), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), stream())
+         float(pro_p), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(seed_base), stream())
 
 
 def ln_stats(x, gamma, beta):
@@ -621,7 +627,7 @@ def ln_stats(x, gamma, beta):
     return mean, rstd
 
 
-def ln_backward(dy, x, mean, rstd, gamma, dres, dgamma, dbeta, mask=None, beta=None):
+def ln_backward(dy, x, mean, rstd, gamma, dres, dgamma, dbeta, mask=None, beta=None, seed_base=None):
     """dx = dLN(dy) (+ dres); dgamma/dbeta accumulated in place.  mask = (seed, p): also returns dx * dropout-mask
     (the gradient in front of the dropout that produced this tensor) -> (dx, dx_masked).  `beta` given: ALSO returns
     xn = LN(x) (appended), for the weight-gradient launch of the Linear behind this LayerNorm (hwgat_ln_bwd_xn)."""
@@ -632,12 +638,13 @@ def ln_backward(dy, x, mean, rstd, gamma, dres, dgamma, dbeta, mask=None, beta=N
         xn = torch.empty_like(x)
         call("hwgat_ln_bwd_xn", ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(dres), ptr(dx),
              ptr(dgamma), ptr(dbeta), x.numel() // d, d, dtype_code(x), ptr(dxm), (mask[0] if mask else 0) & 0xFFFFFFFF,
-             float(mask[1]) if mask else 0.0, ptr(xn), stream())
+             float(mask[1]) if mask else 0.0, ptr(xn), ptr(seed_base), stream())
         return (dx, dxm, xn) if mask is not None else (dx, xn)
     if mask is not None:
         dxm = torch.empty_like(x)
         call("hwgat_ln_bwd_masked", ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(dres), ptr(dx),
-             ptr(dgamma), ptr(dbeta), x.numel() // d, d, dtype_code(x), ptr(dxm), mask[0] & 0xFFFFFFFF, float(mask[1]), stream())
+             ptr(dgamma), ptr(dbeta), x.numel() // d, d, dtype_code(x), ptr(dxm), mask[0] & 0xFFFFFFFF, float(mask[1]),
+             ptr(seed_base), stream())
         return dx, dxm
     call("hwgat_ln_bwd", ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(dres), ptr(dx),
          ptr(dgamma), ptr(dbeta), x.numel() // d, d, dtype_code(x), stream())
@@ -660,7 +667,27 @@ def transpose(W, dtype=torch.float32):
     return out if dtype == torch.float32 else out.to(dtype)
 
 
-def dropout_mask(shape, seed, p, device):
+def dropout_mask(shape, seed, p, device, seed_base=None):
     out = torch.empty(shape, device=device, dtype=torch.float32)
-    call("hwgat_dropout_mask_f32", ptr(out), out.numel(), seed & 0xFFFFFFFF, float(p), stream())
+    call("hwgat_dropout_mask_f32", ptr(out), out.numel(), seed & 0xFFFFFFFF, float(p), ptr(seed_base), stream())
     return out
+
+
+# ---------------------------------------------------------------- device-resident dropout seed
+SEED_C1, SEED_C2, SEED_C3, SEED_SITE = 0x9E3779B1, 0x85EBCA77, 0x27D4EB2F, 0xC2B2AE35
+
+
+def seed_base_value(initial, counter, salt):
+    """host mirror of what hwgat_seed_set / hwgat_seed_advance leave in state[1]"""
+    return (initial * SEED_C1 + counter * SEED_C2 + salt * SEED_C3) & 0xFFFFFFFF
+
+
+def seed_set(state, counter, initial, salt):
+    """state (4 int32 device words) <- {counter, base(counter), initial, salt}: the eager path, all four from host
+    integers passed as kernel arguments (no H2D copy, no sync)"""
+    call("hwgat_seed_set", ptr(state), counter & 0xFFFFFFFF, initial & 0xFFFFFFFF, salt & 0xFFFFFFFF, stream())
+
+
+def seed_advance(state):
+    """counter += 1 and the new base, on the device: the form a captured train step replays"""
+    call("hwgat_seed_advance", ptr(state), stream())

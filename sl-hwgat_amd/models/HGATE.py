@@ -97,6 +97,8 @@ class Model(_base.Model):
         self.activation_dtype = torch.float32
         self.threshold_override = None
         self._drop_calls = 0
+        self.register_buffer("_seed_state", torch.zeros(4, dtype=torch.int32), persistent=False)   # see HWGATE.Model
+        self.device_seed_counter = False
         self.deterministic_eval = True
         if device is not None:
             self.to(device)

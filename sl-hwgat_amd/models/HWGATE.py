@@ -124,6 +124,10 @@ class Model(nn.Module):
         self.activation_dtype = torch.float32
         self.threshold_override: Optional[List[float]] = None    # tests: inject train thresholds
         self._drop_calls = 0
+        # the dropout seed lives on the DEVICE: {step counter, base seed of the step, initial seed, rank salt}; every
+        # seeded kernel adds word 1 to its (host, per-site) seed when it runs, see include/hwgat_hip.h "dropout seeds"
+        self.register_buffer("_seed_state", torch.zeros(4, dtype=torch.int32), persistent=False)
+        self.device_seed_counter = False                          # True: a captured train step advances the counter itself
         self.deterministic_eval = True                            # eval(): fixed-order sums, bit-reproducible logits
         if device is not None:
             self.to(device)
@@ -145,14 +149,34 @@ class Model(nn.Module):
     # ------------------------------------------------------------ forward
     attn_drop_rate = 0.0      # the sibling models (HGATE / WGATE constructors) have no attention dropout
 
+    def _site_seeds(self, k):
+        """four dropout-SITE seeds of block k (host integers that never change): proj, fc1, fc2 outputs
+        (HWGATE.py:116,133,135) and the attention probabilities (HWGATE.py:112).  A kernel hashes with
+        site seed + the base seed of the step, which it reads from `_seed_state[1]` on the device."""
+        return [((k * 4 + s) * HF.SEED_SITE) & 0xFFFFFFFF for s in range(4)]
+
     def _seeds(self, k):
-        """four dropout-site seeds for block k of this forward call (host integers, no sync): proj, fc1, fc2 outputs
-        (HWGATE.py:116,133,135) and the attention probabilities (HWGATE.py:112)"""
+        """the four EFFECTIVE seeds of block k for the step whose counter is `_drop_calls` (host mirror of the device
+        word: site seed + base; what hwgat_dropout_mask_f32 needs to reproduce a mask in a test)"""
         # rank_salt: data-parallel ranks share torch's seed (identical initial weights) but must not share
         # dropout masks (SURVEY 8e); dist.broadcast_parameters() sets it to the rank
-        base = (torch.initial_seed() * 0x9E3779B1 + self._drop_calls * 0x85EBCA77
-                + getattr(self, "rank_salt", 0) * 0x27D4EB2F) & 0xFFFFFFFF
-        return [(base + (k * 4 + s) * 0xC2B2AE35) & 0xFFFFFFFF for s in range(4)]
+        base = HF.seed_base_value(torch.initial_seed(), self._drop_calls, getattr(self, "rank_salt", 0))
+        return [(base + s) & 0xFFFFFFFF for s in self._site_seeds(k)]
+
+    def _seed_base(self):
+        """the 1-element device view the kernels read the step's base seed from"""
+        return self._seed_state[1:2]
+
+    def _next_step_seed(self):
+        """once per train-mode forward.  Eager: the host counter goes up and the four state words are rewritten from host
+        integers (kernel arguments -- no copy, no sync).  `device_seed_counter` (a captured train step, train.GraphedTrainStep):
+        the device increments its own counter, so a graph replay draws fresh masks; the host counter is then only a mirror
+        that the step object keeps in step."""
+        if self.device_seed_counter:
+            HF.seed_advance(self._seed_state)
+        else:
+            self._drop_calls += 1
+            HF.seed_set(self._seed_state, self._drop_calls, torch.initial_seed(), getattr(self, "rank_salt", 0))
 
     def block_list(self):
         """every PartAttentionBlock container in execution order (what functional.weight_prep derives the copies of)"""
@@ -170,13 +194,14 @@ class Model(nn.Module):
         have = hand.stats if hand.of is h else None
         carrier, up = (hand.carrier, hand.up) if (hand.of is h and hand.carrier is not None) else (None, None)
         want, merge = hand.plan.get(k, (False, False))
-        seeds = self._seeds(k)
+        seeds = self._site_seeds(k)
         out, st, oc = fused_block(h, thr, blk, self._mask_bits, n_heads, shifted, p, seeds, self._attn_kind,
                                   stats=have, want_stats=want, merge_out=merge, return_stats=True,
                                   carrier=carrier, up=up, carry_out=(want or k == hand.last_block) and not merge,
                                   return_carrier=True, book=hand.book, deterministic=hand.deterministic,
                                   attn_p=self.attn_drop_rate if self.training else 0.0,
-                                  prep=hand.prep.per_block[k] if hand.prep is not None else None)
+                                  prep=hand.prep.per_block[k] if hand.prep is not None else None,
+                                  seed_base=hand.seed_base)
         hand.of, hand.stats, hand.carrier, hand.up = out, st, oc, ((seeds[2], p) if oc is not None else None)
         return out
 
@@ -191,9 +216,10 @@ class Model(nn.Module):
         x = x.contiguous().float()
         pe = self.pos_encoder.pe.view(self.temporal_dim, self.embed_dim) if self.pe else None
         if self.training:
-            self._drop_calls += 1
+            self._next_step_seed()
         p_pe = self.drop_rate if (self.training and self.pe) else 0.0     # Dropout lives in PositionalEncoding
-        return HF.embed(x, idx, self.B, pe, self.num_kps, self.activation_dtype, p_pe, self._seeds(63)[0])
+        return HF.embed(x, idx, self.B, pe, self.num_kps, self.activation_dtype, p_pe, self._site_seeds(63)[0],
+                        seed_base=self._seed_base() if self.training else None)
 
     def forward_features(self, x):
         h = self._embed(x)
@@ -201,6 +227,7 @@ class Model(nn.Module):
         hand = HF.HandOver(last_block=n_blocks - 1, deterministic=self.deterministic_eval and not self.training)
         # every derived copy of the block weights this call needs (LayerNorm folds, bf16 copies, transposes for the backward)
         hand.prep = HF.weight_prep(self, self.block_list(), self.activation_dtype, torch.is_grad_enabled())
+        hand.seed_base = self._seed_base() if self.training else None
         kk = 0
         for i, stage in enumerate(self.layers):          # every block but the last feeds a LayerNorm; stage ends merge
             for j in range(len(stage.blocks)):
@@ -221,7 +248,7 @@ class Model(nn.Module):
                 h = HF.temporal_merge(h)                  # the fc2 epilogue could not store merged (ragged M)
         if hand.of is h and hand.carrier is not None:
             return HF.ln_mean_pool(h, self.norm.weight, self.norm.bias, carrier=hand.carrier, up=hand.up, book=hand.book,
-                                   deterministic=hand.deterministic)
+                                   deterministic=hand.deterministic, seed_base=hand.seed_base)
         return HF.ln_mean_pool(h, self.norm.weight, self.norm.bias, deterministic=hand.deterministic)
 
     def forward(self, x):

@@ -82,6 +82,8 @@ class Model(_base.Model):
         self.activation_dtype = torch.float32
         self.threshold_override = None
         self._drop_calls = 0
+        self.register_buffer("_seed_state", torch.zeros(4, dtype=torch.int32), persistent=False)   # see HWGATE.Model
+        self.device_seed_counter = False
         self.deterministic_eval = True
         if device is not None:
             self.to(device)
@@ -93,11 +95,12 @@ class Model(_base.Model):
         h = self._embed(x)
         hand = HF.HandOver(last_block=self.depths - 1, deterministic=self.deterministic_eval and not self.training)
         hand.prep = HF.weight_prep(self, self.block_list(), self.activation_dtype, torch.is_grad_enabled())
+        hand.seed_base = self._seed_base() if self.training else None
         for k in range(self.depths):                   # every block but the last feeds the next block's LayerNorm
             hand.plan[k] = (k < self.depths - 1, False)
         for k, blk in enumerate(self.layers):          # PartAttentionBlock.forward, WGATE.py:150-160
             h = self._block(h, blk, self.num_heads, False, None, k, hand)
         if hand.of is h and hand.carrier is not None:
             return HF.ln_mean_pool(h, self.norm.weight, self.norm.bias, carrier=hand.carrier, up=hand.up, book=hand.book,
-                                   deterministic=hand.deterministic)
+                                   deterministic=hand.deterministic, seed_base=hand.seed_base)
         return HF.ln_mean_pool(h, self.norm.weight, self.norm.bias, deterministic=hand.deterministic)

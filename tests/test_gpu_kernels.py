@@ -161,8 +161,8 @@ def test_window_attention_with_attention_dropout(hd, nH, nW, F, B, shifted):
         HF.window_attention(x.detach(), bits, None, nH, shifted, drop=(seed, p_drop))
     L = hw._lib
     o = torch.empty(B, F, K, d, device=DEV)
-    assert L.lib().hwgat_win_attn_fwd_drop(L.ptr(x), L.ptr(o), L.ptr(bits), None, B, F, nW, nH, hd, int(shifted), 0, seed, p_drop, None) < 0
-    assert L.lib().hwgat_win_attn_fwd_drop(L.ptr(x), L.ptr(o), L.ptr(bits), L.ptr(thr_t), B, F, nW, nH, hd, int(shifted), 0, seed, 1.0, None) < 0
+    assert L.lib().hwgat_win_attn_fwd_drop(L.ptr(x), L.ptr(o), L.ptr(bits), None, B, F, nW, nH, hd, int(shifted), 0, seed, p_drop, None, None) < 0
+    assert L.lib().hwgat_win_attn_fwd_drop(L.ptr(x), L.ptr(o), L.ptr(bits), L.ptr(thr_t), B, F, nW, nH, hd, int(shifted), 0, seed, 1.0, None, None) < 0
 
 
 def test_window_attention_edge_rows():
@@ -258,7 +258,7 @@ def test_masked_gradient_copies_equal_gradient_times_dropout_mask(d, dtype):
     L.call("hwgat_ln_bwd", L.ptr(dy), L.ptr(x), L.ptr(mean), L.ptr(rstd), L.ptr(w), L.ptr(res), L.ptr(dx0),
            L.ptr(dg[0]), L.ptr(dg[1]), n, d, dc, L.stream())
     L.call("hwgat_ln_bwd_masked", L.ptr(dy), L.ptr(x), L.ptr(mean), L.ptr(rstd), L.ptr(w), L.ptr(res), L.ptr(dx1),
-           L.ptr(dg[2]), L.ptr(dg[3]), n, d, dc, L.ptr(dxm), seed, p, L.stream())
+           L.ptr(dg[2]), L.ptr(dg[3]), n, d, dc, L.ptr(dxm), seed, p, None, L.stream())
     assert torch.equal(dx0, dx1) and torch.allclose(dg[0], dg[2], rtol=1e-5, atol=1e-5)
     if dtype == torch.float32:
         assert masked_ok(dx1, dxm, (n, d))
@@ -270,7 +270,7 @@ def test_masked_gradient_copies_equal_gradient_times_dropout_mask(d, dtype):
     merged = torch.randn(B, F // 2, K, 2 * d, generator=g).to(DEV).to(dtype)
     nat0, nat1, natm = (torch.empty(B, F, K, d, device=DEV, dtype=dtype) for _ in range(3))
     L.call("hwgat_merge", L.ptr(merged), L.ptr(nat0), B, F, K, d, 1, dc, L.stream())
-    L.call("hwgat_unmerge_masked", L.ptr(merged), L.ptr(nat1), L.ptr(natm), B, F, K, d, dc, seed, p, L.stream())
+    L.call("hwgat_unmerge_masked", L.ptr(merged), L.ptr(nat1), L.ptr(natm), B, F, K, d, dc, seed, p, None, L.stream())
     assert torch.equal(nat0, nat1)
     assert masked_ok(nat1, natm, (B, F, K, d))
     # --- pooled LayerNorm backward
@@ -281,7 +281,7 @@ def test_masked_gradient_copies_equal_gradient_times_dropout_mask(d, dtype):
     p0, p1, pm = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
     L.call("hwgat_lnpool_bwd", L.ptr(gvec), L.ptr(x), L.ptr(mean), L.ptr(rstd), L.ptr(p0), B, n_tok, d, dc, L.stream())
     L.call("hwgat_lnpool_bwd_masked", L.ptr(gvec), L.ptr(x), L.ptr(mean), L.ptr(rstd), L.ptr(p1), B, n_tok, d, dc, L.ptr(pm),
-           seed, p, L.stream())
+           seed, p, None, L.stream())
     assert torch.equal(p0, p1)
     if dtype == torch.float32:
         assert masked_ok(p1, pm, (B, n_tok, d))

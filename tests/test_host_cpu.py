@@ -87,15 +87,15 @@ def test_c_abi_rejects_bad_arguments_without_launching():
     assert L.hwgat_win_attn_bwd(p, p, p, p, None, 1, 4, 1, 2, 64, 0, 7, None) == -3          # HWGAT_EDTYPE
     assert L.hwgat_ln_fwd(p, p, p, p, p, p, 8, 100, 0, None) == -2                           # width 100
     assert L.hwgat_linear_nt_f32(p, p, None, p, 128, 100, 128, 0, None, None, None, None, 0, 0.0, 0,
-                                 None, None, None, 0, 0.0, None) == -2                        # N % 128 (any M is fine)
+                                 None, None, None, 0, 0.0, None, None) == -2                        # N % 128 (any M is fine)
     assert L.hwgat_linear_nt_f32(p, p, None, p, 0, 128, 128, 0, None, None, None, None, 0, 0.0, 0,
-                                 None, None, None, 0, 0.0, None) == -1                        # M <= 0
+                                 None, None, None, 0, 0.0, None, None) == -1                        # M <= 0
     assert L.hwgat_linear_nt_f32(p, p, None, p, 128, 128, 128, 1, None, None, None, None, 0, 0.0, 0,
-                                 None, None, None, 0, 0.0, None) == -1                        # LN prologue w/o stats
+                                 None, None, None, 0, 0.0, None, None) == -1                        # LN prologue w/o stats
     assert L.hwgat_linear_nt_f32(p, p, None, p, 128, 128, 128, 0, None, None, None, None, 0, 0.0, 1,
-                                 None, None, None, 0, 1.5, None) == -1                        # residual missing / p >= 1
-    assert L.hwgat_linear_tn_f32(p, p, p, None, 64, 128, 100, 0, 0.0, None, None, None, None, None) == -2
-    assert L.hwgat_embed_fwd(p, None, p, None, p, 1, 4, 29, 64, 2, 128, 0, 0, 0.0, None) == -2   # J != K without a table
+                                 None, None, None, 0, 1.5, None, None) == -1                        # residual missing / p >= 1
+    assert L.hwgat_linear_tn_f32(p, p, p, None, 64, 128, 100, 0, 0.0, None, None, None, None, None, None) == -2
+    assert L.hwgat_embed_fwd(p, None, p, None, p, 1, 4, 29, 64, 2, 128, 0, 0, 0.0, None, None) == -2   # J != K without a table
     assert L.hwgat_merge(p, p, 1, 3, 16, 128, 0, 0, None) == -2
 
 

@@ -26,7 +26,7 @@ for K in (128, 512, 1536):
     os.environ["HWGAT_NT8W_DBG"] = "5"
     for _ in range(3):
         L.call("hwgat_linear_nt_bf16", L.ptr(A), L.ptr(W), None, L.ptr(out), M, N, K, 0, None, None, None, None, 0, 0.0, 4, None,
-               L.ptr(st), None, 0, 0.0, L.stream())
+               L.ptr(st), None, 0, 0.0, None, L.stream())
     torch.cuda.synchronize()
     s = st.view(256, 8, 2, 6).cpu().double()
     tiles = 5
