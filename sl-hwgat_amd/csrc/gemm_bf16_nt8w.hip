@@ -173,6 +173,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8w_bf16_k(NtArgsB p) {
                 stamps[((blockIdx.x * 8 + stamp_slot) * 2 + gm) * 6 + which] = __builtin_amdgcn_s_memtime();
         }
     };
+    // Epilogue stores and the counted DMA waits (round 4).  vmcnt retires IN ORDER and counts stores: a wait that retires a
+    // DMA stage issued after an epilogue store also waits for that store's acknowledgement, i.e. for the tile's output to
+    // drain to L2 / HBM.  So (a) the stages of the next tile that can be issued BEFORE the stores are (the second halves
+    // of its K-tile 1: their LDS regions are free once phase 8 is through), and (b) the waits of the next tile's phases
+    // 1-5 allow for the NST store instructions that sit between the stages they retire and the ones they may leave in
+    // flight: the first wait that has to see the stores acknowledged is phase 6's -- five phases of main loop later.
+    constexpr int NST = (EPI == EPI_BIAS_GELU_DROP || EPI == EPI_BIAS_GELU_DROP_G) ? 32 : 16;   // store instructions per wave and tile (lower bound)
     int t = blockIdx.x;
     if (t >= n_tiles) return;
     int64_t m0; int n0;
@@ -181,9 +188,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8w_bf16_k(NtArgsB p) {
 
     // ---- prologue: what phases 3..8 of a previous iteration would have issued for this tile's first two K-tiles
     stage_x(0, 0, xc, 0); stage_w(0, 0, wc, 0); stage_x(0, 1, xc, 0); stage_w(0, 1, wc, 0);
-    stage_x(1, 0, xc, 2 * BK); stage_w(1, 0, wc, 2 * BK);
-    wait_vm<4>();                                           // K-tile 0 has landed (this wave's pieces) ...
-    wg_barrier();                                           // ... and everyone's
+    stage_x(1, 0, xc, 2 * BK); stage_w(1, 0, wc, 2 * BK); stage_x(1, 1, xc, 2 * BK); stage_w(1, 1, wc, 2 * BK);
+    wait_vm<0>();                                           // the first tile starts with both K-tiles landed: its first-iteration
+    wg_barrier();                                           // waits (which allow for NST stores that are not there) have nothing to retire
 
     while (true) {
 #pragma unroll
@@ -215,29 +222,32 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8w_bf16_k(NtArgsB p) {
             // makes every wave's pieces visible, one whole phase before the first read.  A region is restaged two or
             // more phases after its last read.
 #define HWGAT_WAIT(NLAST) do { if constexpr (DBG < 2) { if (more) wait_vm<6>(); else wait_vm<NLAST>(); } } while (0)
+            // first iteration after an epilogue: K-tile 1's second halves were staged ahead of the stores (see NST above), phases
+            // 1-2 issue nothing, and the waits count the stores in: outstanding and younger than the stage a wait retires are
+            //   phase 1: sx(1,0) sw(1,0) sx(1,1) sw(1,1) + stores      phase 2: one stage less      phase 3: + this phase's stage ...
+#define HWGAT_WAIT_R(NMORE, NLAST) do { if constexpr (DBG < 2) { if (more) wait_vm<NMORE + NST>(); else wait_vm<NLAST + NST>(); } } while (0)
+            const bool res_it = it == 0;                    // K-tile B's second halves are already staged (prologue / before the epilogue)
             // phase 1: K-tile A (buffer 0), quadrant (X0, W0)
             read_x(0, 0); read_w(0, 0);
-            stage_x(1, 1, xc, kb_c);
-            HWGAT_WAIT(6);
+            if (res_it) { HWGAT_WAIT_R(8, 8); } else { stage_x(1, 1, xc, kb_c); HWGAT_WAIT(6); }
             wg_barrier(); wait_lds(); __builtin_amdgcn_sched_barrier(0); mfma16(0, 0); wg_barrier();
             // phase 2: (X1, W0)
             read_x(0, 1);
-            stage_w(1, 1, wc, kb_c);
-            HWGAT_WAIT(6);
+            if (res_it) { HWGAT_WAIT_R(6, 6); } else { stage_w(1, 1, wc, kb_c); HWGAT_WAIT(6); }
             wg_barrier(); wait_lds(); __builtin_amdgcn_sched_barrier(0); mfma16(1, 0); wg_barrier();
             // phase 3: (X1, W1)
             read_w(0, 1);
             if (more) stage_x(0, 0, xn, kb_n);
-            HWGAT_WAIT(4);
+            if (res_it) { HWGAT_WAIT_R(6, 4); } else { HWGAT_WAIT(4); }
             wg_barrier(); wait_lds(); __builtin_amdgcn_sched_barrier(0); mfma16(1, 1); wg_barrier();
             // phase 4: (X0, W1) -- nothing to read
             if (more) stage_w(0, 0, wnx, kb_n);
-            HWGAT_WAIT(2);
+            if (res_it) { HWGAT_WAIT_R(6, 2); } else { HWGAT_WAIT(2); }
             wg_barrier(); __builtin_amdgcn_sched_barrier(0); mfma16(0, 1); wg_barrier();
             // phases 5-8: the same on K-tile B (buffer 1)
             read_x(1, 0); read_w(1, 0);
             if (more) stage_x(0, 1, xn, kb_n);
-            HWGAT_WAIT(0);
+            if (res_it) { HWGAT_WAIT_R(6, 0); } else { HWGAT_WAIT(0); }
             wg_barrier(); wait_lds(); __builtin_amdgcn_sched_barrier(0); mfma16(0, 0); wg_barrier();
             read_x(1, 1);
             if (more) stage_w(0, 1, wnx, kb_n);
@@ -251,10 +261,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8w_bf16_k(NtArgsB p) {
             HWGAT_WAIT(0);
             wg_barrier(); __builtin_amdgcn_sched_barrier(0); mfma16(0, 1); wg_barrier();
 #undef HWGAT_WAIT
+#undef HWGAT_WAIT_R
         }
         stamp(2);
         if (gm == 0) wg_barrier();                          // waves 0-3 wait for the partner's last cluster: both groups
                                                             // run the epilogue together (two waves per SIMD share the vector pipe)
+        // the next tile's K-tile 1, second halves (buffer 1, last read in phases 6 / 7): issued here, AHEAD of the epilogue's
+        // stores, so that the waits which retire them need not see the stores acknowledged
+        if (tn < n_tiles) { stage_x(1, 1, xn, 2 * BK); stage_w(1, 1, wnx, 2 * BK); }
 
         // ---- epilogue, straight from the accumulators: acc[mt][t][r] is row m0 + wm*64 + mt*16 + fq*4 + r, column
         // n0 + gm*128 + fr*8 + t -- a lane's eight tiles t of one (mt, r) are 8 consecutive columns (16 bytes), the 16 lanes

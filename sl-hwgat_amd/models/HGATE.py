@@ -64,7 +64,12 @@ class Model(_base.Model):
         for i in range(n_stage):
             d = embed_dim * 2 ** i
             if d not in _base._SUPPORTED_WIDTHS or d % num_heads[i] or (d // num_heads[i]) not in (32, 64):
-                raise NotImplementedError(f"stage width {d} / heads {num_heads[i]} not supported by the HIP kernels")
+                raise NotImplementedError(
+                    f"stage width {d} / heads {num_heads[i]} not supported by the HIP kernels: widths must be in "
+                    f"{_base._SUPPORTED_WIDTHS} (the linears tile their output in 128- / 256-column blocks and the LayerNorm "
+                    f"row maps exist for these widths; embed_dim = 64, the reference constructor's default that no "
+                    f"reference config uses, would need 64-column instantiations -- INTEGRATION.md section 6) and "
+                    f"head_dim in (32, 64)")
             stage = _base._Slot()
             stage.blocks = nn.ModuleList()
             for j in range(depths[i]):

@@ -92,11 +92,15 @@ def test_graphed_train_step_equals_the_eager_step(dtype, kind):
         a, b = float(eager_loss[k]), float(graph_loss[k])
         assert abs(a - b) <= tol * max(1.0, abs(a)), (k, a, b)
     assert float(graph_loss[-1]) < float(graph_loss[0])                                     # and it trains
-    for p1, p2 in zip(m1.parameters(), m2.parameters()):                                     # weights follow the optimizer
+    # weights follow the optimizer: the UPDATE the graphed run applied is the eager run's.  (Entry-wise equality is not a
+    # meaningful bar under Adam: an entry whose gradient is ~0 moves by +-lr per step on the sign of summation-order noise.)
+    num = den = 0.0
+    for a, p1, p2 in zip(w0, m1.parameters(), m2.parameters()):
         if p1.requires_grad:
-            d = (p1.detach() - p2.detach()).abs().max().item()
-            assert d <= (1e-4 if dtype == torch.float32 else 3e-3), d
-    assert any((a - b.detach()).abs().max() > 1e-4 for a, b in zip(w0, m2.parameters()))    # ... and moved
+            u1, u2 = (p1.detach() - a).double(), (p2.detach() - a).double()
+            num += float((u1 - u2).pow(2).sum())
+            den += float(u1.pow(2).sum())
+    assert den > 0 and (num / den) ** 0.5 < (0.02 if dtype == torch.float32 else 0.25), (num / den) ** 0.5
     # shape guard and reallocation guard
     with pytest.raises(ValueError):
         s2(x[:4], y[:4])
