@@ -44,7 +44,7 @@ extern "C" {
  *   2000  round 2: *_ex linears, ln_fold / ln_finalize, epilogues 5 / 6, masked-gradient producers
  *   3000  round 3: see INTEGRATION.md section 3
  *   4000  round 4: every entry point with a dropout seed takes `const uint32_t* seed_base` in front of `stream`;
- *         hwgat_seed_set / hwgat_seed_advance; hwgat_is_lab_build */
+ *         hwgat_seed_set / hwgat_seed_advance; hwgat_is_lab_build; hwgat_blk_attn_*_drop, hwgat_band_attn_*_drop */
 #define HWGAT_ABI_VERSION 4000
 int hwgat_abi_version(void);
 
@@ -176,6 +176,17 @@ int hwgat_blk_attn_bwd(const void* qkv, const void* dO, void* dqkv, const uint32
                        int B, int F, int KJ, int nH, int hd, int shifted, int dtype,
                        void* stream);
 
+/* The same with attention dropout (reference HGATE.py:78,106: nn.Dropout on the softmax output, train mode): the
+ * probabilities are multiplied by mask / (1 - drop_p), mask = the common hash over the element index of the reference's
+ * (B F/2, nH, 2 KJ, 2 KJ) attention tensor (token = frame * KJ + joint): hwgat_dropout_mask_f32(out, B (F/2) nH (2 KJ)^2,
+ * drop_seed, drop_p) returns exactly it.  The backward recomputes the mask.  drop_p = 0: the plain kernels, bit for bit. */
+int hwgat_blk_attn_fwd_drop(const void* qkv, void* o, const uint32_t* maskbits, int B, int F, int KJ, int nH, int hd,
+                            int shifted, int dtype, uint32_t drop_seed, float drop_p, const uint32_t* seed_base,
+                            void* stream);
+int hwgat_blk_attn_bwd_drop(const void* qkv, const void* dO, void* dqkv, const uint32_t* maskbits, int B, int F, int KJ,
+                            int nH, int hd, int shifted, int dtype, uint32_t drop_seed, float drop_p,
+                            const uint32_t* seed_base, void* stream);
+
 /* ---- (f) rank 3, sibling model WGATE: fused BAND attention (MSA.forward of
  * hwgat/models/WGATE.py:87-108) with window_partition / window_reverse (WGATE.py:32-65)
  * as index math.  A WGATE window is one 16-joint part window over ALL F frames with an
@@ -193,6 +204,15 @@ int hwgat_band_attn_fwd(const void* qkv, void* o, const uint64_t* maskrows,
 /* backward: do (B,F,K,nH,hd) -> dqkv (B,F,K,3,nH,hd); probabilities recomputed. */
 int hwgat_band_attn_bwd(const void* qkv, const void* dO, void* dqkv, const uint64_t* maskrows,
                         int B, int F, int nW, int nH, int hd, int dtype, void* stream);
+
+/* The same with attention dropout (reference WGATE.py:81,103): mask over the element index of the reference's DENSE
+ * (B nW, nH, F 16, F 16) attention tensor (token = frame * 16 + joint) -- only the band entries are ever evaluated.
+ * hwgat_dropout_mask_f32(out, B nW nH (F 16)^2, drop_seed, drop_p) is the whole mask. */
+int hwgat_band_attn_fwd_drop(const void* qkv, void* o, const uint64_t* maskrows, int B, int F, int nW, int nH, int hd,
+                             int dtype, uint32_t drop_seed, float drop_p, const uint32_t* seed_base, void* stream);
+int hwgat_band_attn_bwd_drop(const void* qkv, const void* dO, void* dqkv, const uint64_t* maskrows, int B, int F, int nW,
+                             int nH, int hd, int dtype, uint32_t drop_seed, float drop_p, const uint32_t* seed_base,
+                             void* stream);
 
 /* debug: one v_mfma_f32_16x16x4_f32 with a (16x4), b (4x16) row-major -> out (64 lanes x 4 regs) */
 int hwgat_debug_mfma16x16x4(const float* a, const float* b, float* out, void* stream);

@@ -65,9 +65,11 @@ def block_shift_mask(frames: int, K: int, tp: int = 2, shift: int = 1, dtype=tor
     return (tok.unsqueeze(1) == tok.unsqueeze(2)).to(dtype)
 
 
-def block_attention(q, k, v, adj, smask=None):
+def block_attention(q, k, v, adj, smask=None, attn_keep=None):
     """MSA.forward core (HGATE.py:91-107) for q,k,v of shape (B, f, nH, tp*K, hd);
-    adj (tp*K, tp*K) 0/1; smask (f, tp*K, tp*K) 0/1 or None.  Returns o (B, f, tp*K, nH*hd), probs."""
+    adj (tp*K, tp*K) 0/1; smask (f, tp*K, tp*K) 0/1 or None; attn_keep: None, or the attention-dropout factor
+    (B, f, nH, tp*K, tp*K) = mask / (1 - p) that nn.Dropout(attn_drop) applies to the probabilities (HGATE.py:78,106) --
+    injected, so that parity does not depend on a random stream.  Returns o (B, f, tp*K, nH*hd), probs."""
     hd = q.shape[-1]
     s = (q * hd ** -0.5) @ k.transpose(-2, -1)                 # :91-93
     if smask is not None:
@@ -75,7 +77,8 @@ def block_attention(q, k, v, adj, smask=None):
     s = s * adj                                                # :100-102
     s = s.masked_fill(s == 0, NEG_FILL)                        # :104
     p = torch.softmax(s, dim=-1)                               # :105
-    o = p @ v                                                  # :108
+    a = p if attn_keep is None else p * attn_keep              # :106
+    o = a @ v                                                  # :108
     B, f, nH, n, _ = o.shape
     return o.transpose(2, 3).reshape(B, f, n, nH * hd), p
 

@@ -56,13 +56,16 @@ def from_windows(xw: torch.Tensor, frames: int) -> torch.Tensor:
     return xw.reshape(B, nW, frames, WINDOW, d).transpose(1, 2).reshape(B, frames, nW * WINDOW, d)
 
 
-def band_attention(q, k, v, mask):
-    """MSA.forward core (WGATE.py:92-105) for q,k,v (B, nW, nH, T*16, hd); mask (nW, T*16, T*16) additive."""
+def band_attention(q, k, v, mask, attn_keep=None):
+    """MSA.forward core (WGATE.py:92-105) for q,k,v (B, nW, nH, T*16, hd); mask (nW, T*16, T*16) additive;
+    attn_keep: None, or the attention-dropout factor (B, nW, nH, T*16, T*16) = mask / (1 - p) of nn.Dropout(attn_drop)
+    on the probabilities (WGATE.py:81,103), injected."""
     hd = q.shape[-1]
     s = (q * hd ** -0.5) @ k.transpose(-2, -1)                 # :92-94
     s = s + mask[None, :, None]                                # :97-100
     p = torch.softmax(s, dim=-1)                               # :102
-    o = p @ v                                                  # :105
+    a = p if attn_keep is None else p * attn_keep              # :103
+    o = a @ v                                                  # :105
     B, nW, nH, n, _ = o.shape
     return o.transpose(2, 3).reshape(B, nW, n, nH * hd), p
 

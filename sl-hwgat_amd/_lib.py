@@ -40,6 +40,10 @@ _SIGS = {
     "hwgat_blk_attn_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "hwgat_blk_attn_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "hwgat_band_attn_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "hwgat_blk_attn_fwd_drop": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _U, _F, _P, _P],
+    "hwgat_blk_attn_bwd_drop": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _U, _F, _P, _P],
+    "hwgat_band_attn_fwd_drop": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _U, _F, _P, _P],
+    "hwgat_band_attn_bwd_drop": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _U, _F, _P, _P],
     "hwgat_band_attn_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "hwgat_debug_mfma16x16x4": [_P, _P, _P, _P],
     "hwgat_lnpool_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P],

@@ -163,10 +163,11 @@ __device__ __forceinline__ uint32_t vis_q(uint64_t mrow, int g, bool has_prev, b
 }
 
 // =============================================================== forward
-template <typename T, int HD, int PF, int MINW>
+template <typename T, int HD, int PF, int MINW, bool ADROP = false>
 __global__ __launch_bounds__(256, MINW) void band_attn_fwd_k(const T* __restrict__ qkv, T* __restrict__ o,
                                                        const uint64_t* __restrict__ maskrows, BandGeom g,
-                                                       int n_units) {
+                                                       int n_units, AttnDrop ad) {
+    if constexpr (ADROP) ad.seed += seed_base_of(ad.base);
     constexpr int NC = HD / 16;
     const int lane = threadIdx.x & 63, lr = lane & 15, gq = lane >> 4;
     // the wave index is uniform; say so, so that unit decoding and all base pointers live in SGPRs
@@ -224,6 +225,12 @@ __global__ __launch_bounds__(256, MINW) void band_attn_fwd_k(const T* __restrict
                 for (int t = 0; t < 3; ++t) s[t] = dot_rows<NC>(kw[t], q);     // s[t][r] = S[q = lr][key = 4g + r]
                 float m, linv;
                 band_softmax(s, vis_q(mrow, gq, f > 0, f + 1 < g.F), p, m, linv);
+                if constexpr (ADROP) {                           // WGATE.py:103
+                    f32x4v keep[3];
+                    band_keep(keep, ad, un.bw, g.nH, un.head, g.F, f, lr, gq);
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) p[t] *= keep[t];
+                }
                 f32x4v oacc[NC];
 #pragma unroll
                 for (int ct = 0; ct < NC; ++ct) oacc[ct] = f32x4v{0.f, 0.f, 0.f, 0.f};
@@ -246,11 +253,13 @@ __global__ __launch_bounds__(256, MINW) void band_attn_fwd_k(const T* __restrict
 // XPOSE = true: the transposed P / dS tiles (lane = key) come from a wave-private LDS scratch (one 16-byte write
 // and four 4-byte reads per tile and lane) instead of a second pair of MFMA products: 60 instead of 84 MFMAs per
 // frame, no cross-lane statistics.  XPOSE = false is the register-only form described above.
-template <typename T, int HD, int PF, int MINW, bool XPOSE>
+template <typename T, int HD, int PF, int MINW, bool XPOSE, bool ADROP = false>
 __global__ __launch_bounds__(256, MINW) void band_attn_bwd_k(const T* __restrict__ qkv, const T* __restrict__ dO,
                                                        T* __restrict__ dqkv,
                                                        const uint64_t* __restrict__ maskrows, BandGeom g,
-                                                       int n_units) {
+                                                       int n_units, AttnDrop ad) {
+    static_assert(XPOSE || !ADROP, "attention dropout exists for the shipped (LDS-transposed) form only");
+    if constexpr (ADROP) ad.seed += seed_base_of(ad.base);
     constexpr int NC = HD / 16;
     constexpr int XLD = 20;                                      // scratch row stride (floats): 16-byte aligned rows
     __shared__ __attribute__((aligned(16))) float xsm[XPOSE ? 4 * 6 * 16 * XLD : 4];
@@ -339,10 +348,14 @@ __global__ __launch_bounds__(256, MINW) void band_attn_bwd_k(const T* __restrict
                 for (int t = 0; t < 3; ++t) s[t] = dot_rows<NC>(kw[t].k, q.q);
                 float m, linv;
                 band_softmax(s, vis_q(mrow, gq, hp, hn), p, m, linv);
+                // attention dropout: A = D o P went into O = A V, so dP = D o dA (dA = dO V^T) and dV = A^T dO; mask recomputed
+                f32x4v keep[ADROP ? 3 : 1];
+                if constexpr (ADROP) band_keep(keep, ad, un.bw, g.nH, un.head, g.F, f, lr, gq);
                 float delta = 0.f;
 #pragma unroll
                 for (int t = 0; t < 3; ++t) {
                     ds[t] = dot_rows<NC>(kw[t].v, q.go);                       // dP[q = lr][key = 4g + r]
+                    if constexpr (ADROP) ds[t] *= keep[t];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) delta += p[t][r] * ds[t][r];
                 }
@@ -367,7 +380,8 @@ __global__ __launch_bounds__(256, MINW) void band_attn_bwd_k(const T* __restrict
                 if constexpr (XPOSE) {
 #pragma unroll
                     for (int t = 0; t < 3; ++t) {
-                        *reinterpret_cast<f32x4v*>(xs + (t * 16 + lr) * XLD + 4 * gq) = p[t];
+                        if constexpr (ADROP) *reinterpret_cast<f32x4v*>(xs + (t * 16 + lr) * XLD + 4 * gq) = p[t] * keep[t];   // dV takes A = D o P
+                        else *reinterpret_cast<f32x4v*>(xs + (t * 16 + lr) * XLD + 4 * gq) = p[t];
                         *reinterpret_cast<f32x4v*>(xs + ((3 + t) * 16 + lr) * XLD + 4 * gq) = ds[t];
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -440,9 +454,11 @@ extern "C" int hwgat_debug_mfma16x16x4(const float* a, const float* b, float* ou
     HWGAT_LAUNCH_CHECK();
 }
 
-extern "C" int hwgat_band_attn_fwd(const void* qkv, void* o, const uint64_t* maskrows, int B, int F, int nW,
-                                   int nH, int hd, int dtype, void* stream) {
-    if (!qkv || !o || !maskrows) return HWGAT_EINVAL;
+extern "C" int hwgat_band_attn_fwd_drop(const void* qkv, void* o, const uint64_t* maskrows, int B, int F, int nW,
+                                        int nH, int hd, int dtype, uint32_t drop_seed, float drop_p,
+                                        const uint32_t* seed_base, void* stream) {
+    if (!qkv || !o || !maskrows || drop_p < 0.f || drop_p >= 1.f) return HWGAT_EINVAL;
+    const AttnDrop ad = make_drop(drop_seed, drop_p, seed_base);
     if (!band_ok(B, F, nW, nH, hd)) return HWGAT_ESHAPE;
     // enough wavefronts to fill the chip: split the clip into frame segments (1 halo frame of K, V each)
     const int64_t base_units = (int64_t)B * nW * nH;
@@ -459,21 +475,33 @@ extern "C" int hwgat_band_attn_fwd(const void* qkv, void* o, const uint64_t* mas
     static const bool old_b16 = lab_env("HWGAT_BAND_B16") && lab_env("HWGAT_BAND_B16")[0] == '0';
     const int blocks = (int)((units + 3) / 4);
     // prefetch depth / occupancy: A/B on MI355X at B64 T128 K64 (fp32): PF 8 at 2 waves/SIMD 327 us, PF 4 at 3-4 waves/SIMD 295-302 us
-#define FWD(T)                                                                                                  \
-    if (hd == 32) band_attn_fwd_k<T, 32, 4, 1><<<blocks, 256, 0, st>>>((const T*)qkv, (T*)o, maskrows, g, (int)units); \
-    else band_attn_fwd_k<T, 16, 4, 3><<<blocks, 256, 0, st>>>((const T*)qkv, (T*)o, maskrows, g, (int)units);
+#define FWD_ARGS(T) (const T*)qkv, (T*)o, maskrows, g, (int)units, ad
+#define FWD(T)                                                                                       \
+    if (ad.p > 0.f) {                                                                                \
+        if (hd == 32) band_attn_fwd_k<T, 32, 4, 1, true><<<blocks, 256, 0, st>>>(FWD_ARGS(T));       \
+        else band_attn_fwd_k<T, 16, 4, 3, true><<<blocks, 256, 0, st>>>(FWD_ARGS(T));                \
+    } else if (hd == 32) band_attn_fwd_k<T, 32, 4, 1><<<blocks, 256, 0, st>>>(FWD_ARGS(T));          \
+    else band_attn_fwd_k<T, 16, 4, 3><<<blocks, 256, 0, st>>>(FWD_ARGS(T));
     if (dtype == HWGAT_F32) { FWD(float) }
     else if (dtype == HWGAT_BF16) {
-        if (!old_b16) return hwgat_launch_band_fwd_b16(qkv, o, maskrows, B, F, nW, nH, hd, st);
+        if (!old_b16) return hwgat_launch_band_fwd_b16(qkv, o, maskrows, B, F, nW, nH, hd, ad.seed, ad.p, ad.base, st);
         FWD(bf16_t)
     } else return HWGAT_EDTYPE;
 #undef FWD
+#undef FWD_ARGS
     HWGAT_LAUNCH_CHECK();
 }
 
-extern "C" int hwgat_band_attn_bwd(const void* qkv, const void* dO, void* dqkv, const uint64_t* maskrows, int B,
-                                   int F, int nW, int nH, int hd, int dtype, void* stream) {
-    if (!qkv || !dO || !dqkv || !maskrows) return HWGAT_EINVAL;
+extern "C" int hwgat_band_attn_fwd(const void* qkv, void* o, const uint64_t* maskrows, int B, int F, int nW,
+                                   int nH, int hd, int dtype, void* stream) {
+    return hwgat_band_attn_fwd_drop(qkv, o, maskrows, B, F, nW, nH, hd, dtype, 0u, 0.f, nullptr, stream);
+}
+
+extern "C" int hwgat_band_attn_bwd_drop(const void* qkv, const void* dO, void* dqkv, const uint64_t* maskrows, int B,
+                                        int F, int nW, int nH, int hd, int dtype, uint32_t drop_seed, float drop_p,
+                                        const uint32_t* seed_base, void* stream) {
+    if (!qkv || !dO || !dqkv || !maskrows || drop_p < 0.f || drop_p >= 1.f) return HWGAT_EINVAL;
+    const AttnDrop ad = make_drop(drop_seed, drop_p, seed_base);
     if (!band_ok(B, F, nW, nH, hd)) return HWGAT_ESHAPE;
     BandGeom g{F, nW * 16, nW, nH, nH * hd, F, 1};
     const int64_t units = (int64_t)B * nW * nH;
@@ -484,18 +512,27 @@ extern "C" int hwgat_band_attn_bwd(const void* qkv, const void* dO, void* dqkv, 
     // register-only form: PF 2 at 1 wave/SIMD 644 us, PF 2 at 2-3 waves/SIMD 630 us, PF 1 at 2 waves/SIMD 619 us (all issue-bound
     // alike); with the LDS transposes (XPOSE, the default; HWGAT_BAND_XPOSE=0 selects the register-only form) 514 us
     static const bool xpose = !(lab_env("HWGAT_BAND_XPOSE") && lab_env("HWGAT_BAND_XPOSE")[0] == '0');
-#define BWD_ARGS(T) (const T*)qkv, (const T*)dO, (T*)dqkv, maskrows, g, (int)units
+#define BWD_ARGS(T) (const T*)qkv, (const T*)dO, (T*)dqkv, maskrows, g, (int)units, ad
 #define BWD(T)                                                                                       \
+    if (ad.p > 0.f) {                                                                                \
+        if (hd == 32) band_attn_bwd_k<T, 32, 1, 1, true, true><<<blocks, 256, 0, st>>>(BWD_ARGS(T)); \
+        else band_attn_bwd_k<T, 16, 2, 2, true, true><<<blocks, 256, 0, st>>>(BWD_ARGS(T));          \
+    } else                                                                                           \
     if (hd == 32 && xpose) band_attn_bwd_k<T, 32, 1, 1, true><<<blocks, 256, 0, st>>>(BWD_ARGS(T)); \
     else if (hd == 32) band_attn_bwd_k<T, 32, 1, 1, false><<<blocks, 256, 0, st>>>(BWD_ARGS(T));     \
     else if (xpose) band_attn_bwd_k<T, 16, 2, 2, true><<<blocks, 256, 0, st>>>(BWD_ARGS(T));         \
     else band_attn_bwd_k<T, 16, 2, 2, false><<<blocks, 256, 0, st>>>(BWD_ARGS(T));
     if (dtype == HWGAT_F32) { BWD(float) }
     else if (dtype == HWGAT_BF16) {
-        if (!old_b16) return hwgat_launch_band_bwd_b16(qkv, dO, dqkv, maskrows, B, F, nW, nH, hd, st);
+        if (!old_b16) return hwgat_launch_band_bwd_b16(qkv, dO, dqkv, maskrows, B, F, nW, nH, hd, ad.seed, ad.p, ad.base, st);
         BWD(bf16_t)
     } else return HWGAT_EDTYPE;
 #undef BWD
 #undef BWD_ARGS
     HWGAT_LAUNCH_CHECK();
+}
+
+extern "C" int hwgat_band_attn_bwd(const void* qkv, const void* dO, void* dqkv, const uint64_t* maskrows, int B,
+                                   int F, int nW, int nH, int hd, int dtype, void* stream) {
+    return hwgat_band_attn_bwd_drop(qkv, dO, dqkv, maskrows, B, F, nW, nH, hd, dtype, 0u, 0.f, nullptr, stream);
 }

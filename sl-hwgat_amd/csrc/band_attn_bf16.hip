@@ -222,6 +222,7 @@ __device__ __forceinline__ void wg_barrier() { asm volatile("s_barrier" ::: "mem
 struct Group16 {
     int64_t tok0;
     int hg, w, f0, f1;
+    int bw;                // clip * nW + window (see BandUnit)
 };
 __device__ __forceinline__ Group16 decode_group(const BandGeom& g, int blk) {
     Group16 r;
@@ -230,6 +231,7 @@ __device__ __forceinline__ Group16 decode_group(const BandGeom& g, int blk) {
     int t = blk / n_hg;
     const int sgi = t % g.n_seg;
     t /= g.n_seg;
+    r.bw = t;
     r.w = t % g.nW;
     const int b = t / g.nW;
     r.tok0 = (int64_t)b * g.F * g.K + r.w * 16;
@@ -240,10 +242,11 @@ __device__ __forceinline__ Group16 decode_group(const BandGeom& g, int blk) {
 
 // =============================================================== forward
 // DBG (kernel lab only): 1 = memory only (stage, read, store; no products, no softmax)
-template <int HD, int PF, int MINW, int DBG = 0>
+template <int HD, int PF, int MINW, int DBG = 0, bool ADROP = false>
 __global__ __launch_bounds__(256, MINW) void band_fwd_st_k(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
                                                            const uint64_t* __restrict__ maskrows, BandGeom g,
-                                                           int64_t qkv_bytes) {
+                                                           int64_t qkv_bytes, AttnDrop ad) {
+    if constexpr (ADROP) ad.seed += seed_base_of(ad.base);
     constexpr int NC = HD / 16;
     using St = Staged<HD>;
     constexpr int WPF = 4 / PF;                                  // waves sharing the DMA work of one frame
@@ -350,6 +353,12 @@ __global__ __launch_bounds__(256, MINW) void band_fwd_st_k(const bf16_t* __restr
 #pragma unroll
                 for (int t = 0; t < 3; ++t) s[t] = dot_rows16<NC>(kw[t], q);   // s[t][r] = S[q = lr][key = 4g + r]
                 const float inv = band_exp<HD>(s, bias, f > 0, f + 1 < g.F, e);
+                if constexpr (ADROP) {                           // WGATE.py:103 (on the numerators: 1 / sum is applied to O)
+                    f32x4v keep[3];
+                    band_keep(keep, ad, un.bw, g.nH, head, g.F, f, lr, gq);
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) e[t] *= keep[t];
+                }
                 f32x4v oacc[NC];
 #pragma unroll
                 for (int ct = 0; ct < NC; ++ct) oacc[ct] = f32x4v{0.f, 0.f, 0.f, 0.f};
@@ -665,11 +674,12 @@ __global__ __launch_bounds__(256, 4) void band_memtest_k(const bf16_t* __restric
 // the query frames [f0, f1) and dk, dv of the key frames [f0, f1).
 // Staged per query frame: Q, dO of that frame and K, V of the frame after it (4 tiles of 4 heads); the column forms come
 // from the same LDS images by transposed reads, so only P and dS pass through the wave-private transposing tiles.
-template <int HD, int PF, int MINW>
+template <int HD, int PF, int MINW, bool ADROP = false>
 __global__ __launch_bounds__(256, MINW) void band_bwd_st_k(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
                                                            bf16_t* __restrict__ dqkv,
                                                            const uint64_t* __restrict__ maskrows, BandGeom g,
-                                                           int64_t qkv_bytes, int64_t do_bytes) {
+                                                           int64_t qkv_bytes, int64_t do_bytes, AttnDrop ad) {
+    if constexpr (ADROP) ad.seed += seed_base_of(ad.base);
     constexpr int NC = HD / 16;
     using St = Staged<HD>;
     constexpr int WPF = 4 / PF;                                  // waves sharing the DMA work of one frame
@@ -802,11 +812,15 @@ __global__ __launch_bounds__(256, MINW) void band_bwd_st_k(const bf16_t* __restr
 #pragma unroll
                 for (int t = 0; t < 3; ++t) s[t] = dot_rows16<NC>(kw[t].k, q);
                 const float inv = band_exp<HD>(s, bias, hp, hn, p);
+                // attention dropout: A = D o P went into O = A V, so dP = D o dA (dA = dO V^T) and dV = A^T dO; mask recomputed
+                f32x4v keep[ADROP ? 3 : 1];
+                if constexpr (ADROP) band_keep(keep, ad, un.bw, g.nH, head, g.F, f, lr, gq);
                 float delta = 0.f;
 #pragma unroll
                 for (int t = 0; t < 3; ++t) {
                     p[t] *= inv;
                     ds[t] = dot_rows16<NC>(kw[t].v, go);                       // dP[q = lr][key = 4g + r]
+                    if constexpr (ADROP) ds[t] *= keep[t];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) delta = __builtin_fmaf(p[t][r], ds[t][r], delta);
                 }
@@ -815,7 +829,8 @@ __global__ __launch_bounds__(256, MINW) void band_bwd_st_k(const bf16_t* __restr
 #pragma unroll
                 for (int t = 0; t < 3; ++t) {
                     ds[t] = p[t] * (ds[t] - delta);                            // dS (the score scale goes on dq / dk)
-                    pb[t] = to_bf(p[t]);
+                    if constexpr (ADROP) pb[t] = to_bf(p[t] * keep[t]);        // the transposed P feeds dV only: A = D o P
+                    else pb[t] = to_bf(p[t]);
                     dsb[t] = to_bf(ds[t]);
                     xp.write(tp + t * TTILE, pb[t]);
                     xp.write(td + t * TTILE, dsb[t]);
@@ -866,15 +881,18 @@ int segments(int64_t base_units, int F, int64_t want, int min_seg, const char* l
 }
 
 template <int HD, int PF, int MINW, int DBG = 0>
-int launch_fwd_st(const bf16_t* x, bf16_t* o, const uint64_t* maskrows, const BandGeom& g, int blocks, int64_t bytes, hipStream_t st) {
-    band_fwd_st_k<HD, PF, MINW, DBG><<<blocks, 256, 0, st>>>(x, o, maskrows, g, bytes);
+int launch_fwd_st(const bf16_t* x, bf16_t* o, const uint64_t* maskrows, const BandGeom& g, int blocks, int64_t bytes,
+                  const AttnDrop& ad, hipStream_t st) {
+    if (ad.p > 0.f) band_fwd_st_k<HD, PF, MINW, DBG, true><<<blocks, 256, 0, st>>>(x, o, maskrows, g, bytes, ad);
+    else band_fwd_st_k<HD, PF, MINW, DBG><<<blocks, 256, 0, st>>>(x, o, maskrows, g, bytes, ad);
     HWGAT_LAUNCH_CHECK();
 }
 
 }  // namespace
 
 int hwgat_launch_band_fwd_b16(const void* qkv, void* o, const uint64_t* maskrows, int B, int F, int nW, int nH, int hd,
-                              hipStream_t st) {
+                              uint32_t drop_seed, float drop_p, const uint32_t* seed_base, hipStream_t st) {
+    const AttnDrop ad = make_drop(drop_seed, drop_p, seed_base);
     const int64_t base_units = (int64_t)B * nW * nH;
     int n_seg = segments(base_units, F, 256 * 4 * 2, 16, "HWGAT_BAND_FSEG");
     const int seg = (F + n_seg - 1) / n_seg;
@@ -894,19 +912,20 @@ int hwgat_launch_band_fwd_b16(const void* qkv, void* o, const uint64_t* maskrows
         else if (dbg == 2) band_fwd_b16_k<16, 4, 4, 2><<<blocks, 256, 0, st>>>(x, (bf16_t*)o, maskrows, g, (int)units);
         else if (dbg == 3) band_fwd_b16_k<16, 4, 4, 3><<<blocks, 256, 0, st>>>(x, (bf16_t*)o, maskrows, g, (int)units);
         else if (dbg == 4) band_memtest_k<4><<<blocks, 256, 0, st>>>(x, (bf16_t*)o, g, (int)units);
-        else if (dbg == 5) return launch_fwd_st<16, 4, 3, 1>(x, (bf16_t*)o, maskrows, g, blocks_st, bytes, st);
-        else if (dbg == 6) return launch_fwd_st<16, 2, 3>(x, (bf16_t*)o, maskrows, g, blocks_st, bytes, st);
+        else if (dbg == 5) return launch_fwd_st<16, 4, 3, 1>(x, (bf16_t*)o, maskrows, g, blocks_st, bytes, ad, st);
+        else if (dbg == 6) return launch_fwd_st<16, 2, 3>(x, (bf16_t*)o, maskrows, g, blocks_st, bytes, ad, st);
         else if (dbg == 7) band_fwd_b16_k<16, 4, 4><<<blocks, 256, 0, st>>>(x, (bf16_t*)o, maskrows, g, (int)units);
-        else return launch_fwd_st<16, 4, 3>(x, (bf16_t*)o, maskrows, g, blocks_st, bytes, st);
+        else return launch_fwd_st<16, 4, 3>(x, (bf16_t*)o, maskrows, g, blocks_st, bytes, ad, st);
         HWGAT_LAUNCH_CHECK();
     }
 #endif
-    if (hd == 32) return launch_fwd_st<32, 2, 2>(x, (bf16_t*)o, maskrows, g, blocks_st, bytes, st);
-    return launch_fwd_st<16, 4, 3>(x, (bf16_t*)o, maskrows, g, blocks_st, bytes, st);
+    if (hd == 32) return launch_fwd_st<32, 2, 2>(x, (bf16_t*)o, maskrows, g, blocks_st, bytes, ad, st);
+    return launch_fwd_st<16, 4, 3>(x, (bf16_t*)o, maskrows, g, blocks_st, bytes, ad, st);
 }
 
 int hwgat_launch_band_bwd_b16(const void* qkv, const void* dO, void* dqkv, const uint64_t* maskrows, int B, int F, int nW,
-                              int nH, int hd, hipStream_t st) {
+                              int nH, int hd, uint32_t drop_seed, float drop_p, const uint32_t* seed_base, hipStream_t st) {
+    const AttnDrop ad = make_drop(drop_seed, drop_p, seed_base);
     const int64_t base_units = (int64_t)B * nW * nH;
     int n_seg = segments(base_units, F, 256 * 4 * 2, 16, "HWGAT_BAND_BSEG");
     const int seg = (F + n_seg - 1) / n_seg;
@@ -917,7 +936,11 @@ int hwgat_launch_band_bwd_b16(const void* qkv, const void* dO, void* dqkv, const
     if (units > 0x7fffffff || clip_bytes > 0x7fffffff) return HWGAT_ESHAPE;
     const bf16_t* x = (const bf16_t*)qkv;
     const int blocks_st = (int)((int64_t)B * nW * n_seg * ((nH + 3) / 4));
-#define BWD_ST(HD, PF, MINW) band_bwd_st_k<HD, PF, MINW><<<blocks_st, 256, 0, st>>>(x, (const bf16_t*)dO, (bf16_t*)dqkv, maskrows, g, clip_bytes * B, clip_bytes * B / 3)
+#define BWD_ST(HD, PF, MINW)                                                                                                  \
+    do {                                                                                                                      \
+        if (ad.p > 0.f) band_bwd_st_k<HD, PF, MINW, true><<<blocks_st, 256, 0, st>>>(x, (const bf16_t*)dO, (bf16_t*)dqkv, maskrows, g, clip_bytes * B, clip_bytes * B / 3, ad); \
+        else band_bwd_st_k<HD, PF, MINW><<<blocks_st, 256, 0, st>>>(x, (const bf16_t*)dO, (bf16_t*)dqkv, maskrows, g, clip_bytes * B, clip_bytes * B / 3, ad); \
+    } while (0)
 #ifdef HWGAT_LAB
     if (const char* e = lab_env("HWGAT_BAND_DBG")) {
         const int blocks = (int)((units + 3) / 4);

@@ -24,6 +24,7 @@
 // at the fp32 MFMA / HBM ridge rather than clearly HBM-bound (HGATE section).
 #include "attn_common.h"
 #include "blk_common.h"
+#include "fused_ops.h"            // the dropout hash (attention dropout, HGATE.py:78,106)
 
 namespace {
 using namespace blk;
@@ -64,6 +65,21 @@ __device__ __forceinline__ uint32_t masked_softmax64(float (&s)[2][16], float (&
     return nz;
 }
 
+// keep[kt][r] = 1/(1-p) or 0 for P[q][key slot kt*32 + crow(r,hh)] of unit u: element ((u * N2 + q) * N2 + key) of the
+// reference's (B f, nH, N2, N2) attention tensor, N2 = 2 KJ tokens per block, token = frame * KJ + joint (HGATE.py:87-106)
+__device__ __forceinline__ void blk_keep(float (&k)[2][16], const AttnDrop& ad, int u, int q_tok, int hh, int KJ) {
+    const uint32_t thresh = drop_thresh(ad.p);
+    const float scale = 1.0f / (1.0f - ad.p);
+    const uint64_t row = ((uint64_t)u * (2 * KJ) + q_tok) * (2 * KJ);
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = crow(r, hh);
+            k[kt][r] = j < KJ ? drop_keep(ad.seed, row + kt * KJ + j, thresh, scale) : 0.f;
+        }
+}
+
 template <typename T, int HD> struct BlkCfg {
     using E = typename tile_of<T>::E;          // LDS tile element: fp32 tiles + fp32 MFMAs, or raw bf16 tiles + bf16 MFMAs (attn_common.h)
     static constexpr int LDW = HD + tile_of<T>::PAD;
@@ -77,10 +93,11 @@ template <typename T, int HD> struct BlkCfg {
 
 // =============================================================== forward
 // Two wavefronts share a unit: wave w loads frame tile w of Q and K and owns query tile w.
-template <typename T, int HD>
+template <typename T, int HD, bool ADROP = false>
 __global__ __launch_bounds__(128, 2) void blk_attn_fwd_k(const T* __restrict__ qkv, T* __restrict__ o,
                                                       const uint32_t* __restrict__ maskbits, BlkGeom g,
-                                                      int n_units) {
+                                                      int n_units, AttnDrop ad) {
+    if constexpr (ADROP) ad.seed += seed_base_of(ad.base);
     using C = BlkCfg<T, HD>;
     constexpr int LDW = C::LDW, NT = C::NT, NLD = C::NLD, RPI = C::RPI, TILE = C::TILE;
     using E = typename C::E;
@@ -142,6 +159,14 @@ __global__ __launch_bounds__(128, 2) void blk_attn_fwd_k(const T* __restrict__ q
             for (int r = 0; r < 16; ++r) s[kt][r] = QS ? st[r] : st[r] * qk_scale<HD>();
         }
         masked_softmax64(s, p, mb0, mb1, hh, g.KJ);
+        if constexpr (ADROP) {                                  // HGATE.py:106
+            float keep[2][16];
+            blk_keep(keep, ad, u, w * g.KJ + lq, hh, g.KJ);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) p[kt][r] *= keep[kt][r];
+        }
 
         f32x16 oacc[NT];
         tile_ay<HD, LDW, true>(p[0], Vs, lq, hh, oacc);           // P fed back as the A operand, V in the B layout from LDS
@@ -165,11 +190,12 @@ __global__ __launch_bounds__(128, 2) void blk_attn_fwd_k(const T* __restrict__ q
 // transposed dS and P tiles meet in a shared scratch tile.  Phase B: wave w owns KEY tile w
 // (dK_w = sum_qt dS^T Q_qt, dV_w = sum_qt P^T dO_qt).  Q, K, dO live in LDS; V is only ever the
 // row-per-lane operand of dP, so it goes from HBM straight into registers.
-template <typename T, int HD>
+template <typename T, int HD, bool ADROP = false>
 __global__ __launch_bounds__(128, sizeof(T) == 2 ? 2 : 1) void blk_attn_bwd_k(const T* __restrict__ qkv, const T* __restrict__ dO,
                                                       T* __restrict__ dqkv,
                                                       const uint32_t* __restrict__ maskbits, BlkGeom g,
-                                                      int n_units) {
+                                                      int n_units, AttnDrop ad) {
+    if constexpr (ADROP) ad.seed += seed_base_of(ad.base);
     using C = BlkCfg<T, HD>;
     constexpr int LDW = C::LDW, NT = C::NT, NLD = C::NLD, RPI = C::RPI, TILE = C::TILE;
     using E = typename C::E;
@@ -259,6 +285,9 @@ __global__ __launch_bounds__(128, sizeof(T) == 2 ? 2 : 1) void blk_attn_bwd_k(co
             for (int r = 0; r < 16; ++r) s[kt][r] = QS ? st[r] : st[r] * qk_scale<HD>();
         }
         const uint32_t nz = masked_softmax64(s, p, mb0, mb1, hh, g.KJ);
+        // attention dropout: A = D o P went into O = A V, so dP = D o dA (dA = dO V^T) and dV = A^T dO; the mask is recomputed
+        float keep[ADROP ? 2 : 1][ADROP ? 16 : 1];
+        if constexpr (ADROP) blk_keep(keep, ad, u, w * g.KJ + lq, hh, g.KJ);
 #pragma unroll
         for (int i = 0; i < NLD; ++i)
             raw_to_lds(Gs + (w * 32 + i * RPI + crow_l) * LDW + ccol, gr[i], 1.0f, T());
@@ -289,7 +318,12 @@ __global__ __launch_bounds__(128, sizeof(T) == 2 ? 2 : 1) void blk_attn_bwd_k(co
                     }
                 }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { ds[kt][r] = dp[r]; delta += p[kt][r] * dp[r]; }
+                for (int r = 0; r < 16; ++r) {
+                    float dpr = dp[r];
+                    if constexpr (ADROP) dpr *= keep[kt][r];
+                    ds[kt][r] = dpr;
+                    delta += p[kt][r] * dpr;
+                }
             }
             delta += partner(delta);
 #pragma unroll
@@ -343,6 +377,12 @@ __global__ __launch_bounds__(128, sizeof(T) == 2 ? 2 : 1) void blk_attn_bwd_k(co
             if (crow(r, hh) < g.KJ) store_nt<T, NT>(gbase + (base_w + crow(r, hh)) * row3d + g.d, ov);
         }
         __syncthreads();                                         // (3) dS scratch consumed
+        if constexpr (ADROP) {
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) p[kt][r] *= keep[kt][r];
+        }
         put(p);
         __syncthreads();                                         // (4) P of both query tiles visible
         // dV_w = sum_qt P[qt][kt = w]^T dO_qt
@@ -371,26 +411,30 @@ bool bgeom_ok(int B, int F, int KJ, int nH, int hd) {
 constexpr int LDS_PER_CU = 160 * 1024;
 
 template <typename T, int HD>
-int launch_bfwd(const void* qkv, void* o, const uint32_t* mb, BlkGeom g, int n_units, hipStream_t st) {
+int launch_bfwd(const void* qkv, void* o, const uint32_t* mb, BlkGeom g, int n_units, AttnDrop ad, hipStream_t st) {
     constexpr int per_cu = LDS_PER_CU / (6 * BlkCfg<T, HD>::TILE * (int)sizeof(typename BlkCfg<T, HD>::E));
     const int blocks = min(n_units, 256 * (per_cu > 8 ? 8 : per_cu));
-    blk_attn_fwd_k<T, HD><<<blocks, 128, 0, st>>>((const T*)qkv, (T*)o, mb, g, n_units);
+    if (ad.p > 0.f) blk_attn_fwd_k<T, HD, true><<<blocks, 128, 0, st>>>((const T*)qkv, (T*)o, mb, g, n_units, ad);
+    else blk_attn_fwd_k<T, HD><<<blocks, 128, 0, st>>>((const T*)qkv, (T*)o, mb, g, n_units, ad);
     HWGAT_LAUNCH_CHECK();
 }
 template <typename T, int HD>
-int launch_bbwd(const void* qkv, const void* dO, void* dqkv, const uint32_t* mb, BlkGeom g, int n_units,
+int launch_bbwd(const void* qkv, const void* dO, void* dqkv, const uint32_t* mb, BlkGeom g, int n_units, AttnDrop ad,
                 hipStream_t st) {
     constexpr int per_cu = LDS_PER_CU / ((6 * BlkCfg<T, HD>::TILE + 64 * 66) * (int)sizeof(typename BlkCfg<T, HD>::E));
     const int blocks = min(n_units, 256 * (per_cu > 4 ? 4 : per_cu));
-    blk_attn_bwd_k<T, HD><<<blocks, 128, 0, st>>>((const T*)qkv, (const T*)dO, (T*)dqkv, mb, g, n_units);
+    if (ad.p > 0.f) blk_attn_bwd_k<T, HD, true><<<blocks, 128, 0, st>>>((const T*)qkv, (const T*)dO, (T*)dqkv, mb, g, n_units, ad);
+    else blk_attn_bwd_k<T, HD><<<blocks, 128, 0, st>>>((const T*)qkv, (const T*)dO, (T*)dqkv, mb, g, n_units, ad);
     HWGAT_LAUNCH_CHECK();
 }
 
 }  // namespace
 
-extern "C" int hwgat_blk_attn_fwd(const void* qkv, void* o, const uint32_t* maskbits, int B, int F, int KJ,
-                                  int nH, int hd, int shifted, int dtype, void* stream) {
-    if (!qkv || !o || !maskbits) return HWGAT_EINVAL;
+extern "C" int hwgat_blk_attn_fwd_drop(const void* qkv, void* o, const uint32_t* maskbits, int B, int F, int KJ,
+                                       int nH, int hd, int shifted, int dtype, uint32_t drop_seed, float drop_p,
+                                       const uint32_t* seed_base, void* stream) {
+    if (!qkv || !o || !maskbits || drop_p < 0.f || drop_p >= 1.f) return HWGAT_EINVAL;
+    const AttnDrop ad = make_drop(drop_seed, drop_p, seed_base);
     if (!bgeom_ok(B, F, KJ, nH, hd)) return HWGAT_ESHAPE;
     BlkGeom g{F, KJ, nH, F / 2, nH * hd, shifted ? 1 : 0};
     const int64_t units = (int64_t)B * g.f * nH;
@@ -398,23 +442,29 @@ extern "C" int hwgat_blk_attn_fwd(const void* qkv, void* o, const uint32_t* mask
     hipStream_t st = (hipStream_t)stream;
 #define FWD(T)                                                                              \
     switch (hd) {                                                                           \
-        case 32: return launch_bfwd<T, 32>(qkv, o, maskbits, g, (int)units, st);            \
-        default: return launch_bfwd<T, 64>(qkv, o, maskbits, g, (int)units, st);            \
+        case 32: return launch_bfwd<T, 32>(qkv, o, maskbits, g, (int)units, ad, st);        \
+        default: return launch_bfwd<T, 64>(qkv, o, maskbits, g, (int)units, ad, st);        \
     }
     if (dtype == HWGAT_F32) { FWD(float) }
     if (dtype == HWGAT_BF16) {
         static const bool old_b16 = lab_env("HWGAT_BLK_B16") && lab_env("HWGAT_BLK_B16")[0] == '0';     // see hwgat_blk_attn_bwd
-        if (hd == 64 && !old_b16) return hwgat_launch_blk_fwd_b16(qkv, o, maskbits, B, F, KJ, nH, shifted, st);
+        if (hd == 64 && !old_b16) return hwgat_launch_blk_fwd_b16(qkv, o, maskbits, B, F, KJ, nH, shifted, ad.seed, ad.p, ad.base, st);
         FWD(bf16_t)
     }
 #undef FWD
     return HWGAT_EDTYPE;
 }
 
-extern "C" int hwgat_blk_attn_bwd(const void* qkv, const void* dO, void* dqkv, const uint32_t* maskbits,
-                                  int B, int F, int KJ, int nH, int hd, int shifted, int dtype,
-                                  void* stream) {
-    if (!qkv || !dO || !dqkv || !maskbits) return HWGAT_EINVAL;
+extern "C" int hwgat_blk_attn_fwd(const void* qkv, void* o, const uint32_t* maskbits, int B, int F, int KJ,
+                                  int nH, int hd, int shifted, int dtype, void* stream) {
+    return hwgat_blk_attn_fwd_drop(qkv, o, maskbits, B, F, KJ, nH, hd, shifted, dtype, 0u, 0.f, nullptr, stream);
+}
+
+extern "C" int hwgat_blk_attn_bwd_drop(const void* qkv, const void* dO, void* dqkv, const uint32_t* maskbits,
+                                       int B, int F, int KJ, int nH, int hd, int shifted, int dtype,
+                                       uint32_t drop_seed, float drop_p, const uint32_t* seed_base, void* stream) {
+    if (!qkv || !dO || !dqkv || !maskbits || drop_p < 0.f || drop_p >= 1.f) return HWGAT_EINVAL;
+    const AttnDrop ad = make_drop(drop_seed, drop_p, seed_base);
     if (!bgeom_ok(B, F, KJ, nH, hd)) return HWGAT_ESHAPE;
     BlkGeom g{F, KJ, nH, F / 2, nH * hd, shifted ? 1 : 0};
     const int64_t units = (int64_t)B * g.f * nH;
@@ -422,17 +472,23 @@ extern "C" int hwgat_blk_attn_bwd(const void* qkv, const void* dO, void* dqkv, c
     hipStream_t st = (hipStream_t)stream;
 #define BWD(T)                                                                                    \
     switch (hd) {                                                                                 \
-        case 32: return launch_bbwd<T, 32>(qkv, dO, dqkv, maskbits, g, (int)units, st);           \
-        default: return launch_bbwd<T, 64>(qkv, dO, dqkv, maskbits, g, (int)units, st);           \
+        case 32: return launch_bbwd<T, 32>(qkv, dO, dqkv, maskbits, g, (int)units, ad, st);       \
+        default: return launch_bbwd<T, 64>(qkv, dO, dqkv, maskbits, g, (int)units, ad, st);       \
     }
     if (dtype == HWGAT_F32) { BWD(float) }
     if (dtype == HWGAT_BF16) {
         // head_dim 64 (every HGATE stage): the 16x16-tile, four-waves-per-unit kernel of blk_attn_bf16.hip; the 32x32-tile
         // form stays for head_dim 32 and as the lab A/B (HWGAT_BLK_B16=0)
         static const bool old_b16 = lab_env("HWGAT_BLK_B16") && lab_env("HWGAT_BLK_B16")[0] == '0';
-        if (hd == 64 && !old_b16) return hwgat_launch_blk_bwd_b16(qkv, dO, dqkv, maskbits, B, F, KJ, nH, shifted, st);
+        if (hd == 64 && !old_b16) return hwgat_launch_blk_bwd_b16(qkv, dO, dqkv, maskbits, B, F, KJ, nH, shifted, ad.seed, ad.p, ad.base, st);
         BWD(bf16_t)
     }
 #undef BWD
     return HWGAT_EDTYPE;
+}
+
+extern "C" int hwgat_blk_attn_bwd(const void* qkv, const void* dO, void* dqkv, const uint32_t* maskbits,
+                                  int B, int F, int KJ, int nH, int hd, int shifted, int dtype,
+                                  void* stream) {
+    return hwgat_blk_attn_bwd_drop(qkv, dO, dqkv, maskbits, B, F, KJ, nH, hd, shifted, dtype, 0u, 0.f, nullptr, stream);
 }

@@ -23,6 +23,7 @@
 #include <stdlib.h>
 #include "blk_common.h"
 #include "attn16_common.h"
+#include "fused_ops.h"            // the dropout hash (attention dropout, HGATE.py:78,106)
 
 namespace {
 using namespace blk;
@@ -60,6 +61,22 @@ __device__ __forceinline__ float masked_exp64(f32x4v (&s)[4], uint32_t mb0, uint
     return xg_sum(sum);
 }
 
+// attention dropout: keep[kt][r] = 1/(1-p) or 0 for P[query slot][key slot 16 kt + 4g + r] of unit u = element
+// ((u * N2 + q) * N2 + key) of the reference's (B f, nH, N2, N2) attention tensor, N2 = 2 KJ, token = frame * KJ + joint
+__device__ __forceinline__ void blk_keep16(f32x4v (&k)[4], const AttnDrop& ad, int u, int q_slot, int gq, int KJ) {
+    const uint32_t thresh = drop_thresh(ad.p);
+    const float scale = 1.0f / (1.0f - ad.p);
+    const int qj = q_slot & 31;
+    const uint64_t row = ((uint64_t)u * (2 * KJ) + (q_slot >> 5) * KJ + (qj < KJ ? qj : KJ - 1)) * (2 * KJ);
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = 16 * (kt & 1) + 4 * gq + r;
+            k[kt][r] = j < KJ ? drop_keep(ad.seed, row + (kt >> 1) * KJ + j, thresh, scale) : 0.f;
+        }
+}
+
 // ---- stage: wave w issues DMA instructions 2w, 2w+1 (8 slot rows each) of each image: Q, K, V (and dO with NIMG = 4)
 template <int NIMG>
 __device__ __forceinline__ void stage_unit(char* sm, const bf16_t* qkv, const bf16_t* dO, const BlkGeom& g, const BUnit& un,
@@ -94,8 +111,11 @@ __device__ __forceinline__ void stage_unit(char* sm, const bf16_t* qkv, const bf
 // =============================================================== forward
 // wave w owns query slots 16w .. 16w+15: S^T = K Q^T, masks + softmax, O^T = V^T P^T (V as a column operand), O rows scaled
 // by 1 / row sum and stored as four consecutive channels per lane.  24 KB of LDS: six workgroups per CU.
+template <bool ADROP>
 __global__ __launch_bounds__(256, 4) void blk_fwd_b16_k(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
-                                                        const uint32_t* __restrict__ maskbits, BlkGeom g, int64_t qkv_bytes) {
+                                                        const uint32_t* __restrict__ maskbits, BlkGeom g, int64_t qkv_bytes,
+                                                        AttnDrop ad) {
+    if constexpr (ADROP) ad.seed += seed_base_of(ad.base);
     __shared__ __attribute__((aligned(1024))) char sm[3 * IMG];  // Q | K | V
     const char* Qt = sm;
     const char* Kt = sm + IMG;
@@ -122,6 +142,12 @@ __global__ __launch_bounds__(256, 4) void blk_fwd_b16_k(const bf16_t* __restrict
     }
     uint32_t nz;
     const float inv = __builtin_amdgcn_rcpf(masked_exp64(s, mb0, mb1, gq, g.KJ, nz));
+    if constexpr (ADROP) {                                       // HGATE.py:106 (on the numerators: 1 / row sum is applied to O)
+        f32x4v keep[4];
+        blk_keep16(keep, ad, blockIdx.x, slot, gq, g.KJ);
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) s[kt] *= keep[kt];
+    }
     u32x2v pb[4];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) pb[kt] = to_bf(s[kt]);       // numerators, rounded to bf16 as MFMA operands
@@ -137,9 +163,11 @@ __global__ __launch_bounds__(256, 4) void blk_fwd_b16_k(const bf16_t* __restrict
 }
 
 // =============================================================== backward
+template <bool ADROP>
 __global__ __launch_bounds__(256, 3) void blk_bwd_b16_k(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
                                                         bf16_t* __restrict__ dqkv, const uint32_t* __restrict__ maskbits,
-                                                        BlkGeom g, int64_t qkv_bytes, int64_t do_bytes) {
+                                                        BlkGeom g, int64_t qkv_bytes, int64_t do_bytes, AttnDrop ad) {
+    if constexpr (ADROP) ad.seed += seed_base_of(ad.base);
     __shared__ __attribute__((aligned(1024))) char sm[6 * IMG];  // Q | K | V | dO | P | dS
     char* Qt = sm;
     char* Kt = sm + IMG;
@@ -177,10 +205,14 @@ __global__ __launch_bounds__(256, 3) void blk_bwd_b16_k(const bf16_t* __restrict
     uint32_t nz;
     const float sum = masked_exp64(s, mb0, mb1, gq, g.KJ, nz);
     const float inv = real ? __builtin_amdgcn_rcpf(sum) : 0.f;          // pad query slots: P = dS = 0
+    // attention dropout: A = D o P went into O = A V, so dP = D o dA (dA = dO V^T, in `dp`) and dV = A^T dO; mask recomputed
+    f32x4v keep[ADROP ? 4 : 1];
+    if constexpr (ADROP) blk_keep16(keep, ad, blockIdx.x, slot, gq, g.KJ);
     float delta = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
         s[kt] *= inv;                                                            // P (HGATE.py:105)
+        if constexpr (ADROP) dp[kt] *= keep[kt];
 #pragma unroll
         for (int r = 0; r < 4; ++r) delta = __builtin_fmaf(s[kt][r], dp[kt][r], delta);
     }
@@ -190,7 +222,8 @@ __global__ __launch_bounds__(256, 3) void blk_bwd_b16_k(const bf16_t* __restrict
     for (int kt = 0; kt < 4; ++kt) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) dp[kt][r] = ((nz >> (4 * kt + r)) & 1u) ? s[kt][r] * (dp[kt][r] - delta) : 0.f;   // dS
-        pb[kt] = to_bf(s[kt]);
+        if constexpr (ADROP) pb[kt] = to_bf(s[kt] * keep[kt]);                   // the P image feeds dV only: A = D o P
+        else pb[kt] = to_bf(s[kt]);
         db[kt] = to_bf(dp[kt]);
         // [query][key] images: keys 16 kt + 4g .. + 3 = 8 bytes at byte column 32 kt + 8 g
         const uint32_t off = chunk_off(slot, 2 * kt + (gq >> 1)) + (gq & 1) * 8;
@@ -245,22 +278,29 @@ __global__ __launch_bounds__(256, 3) void blk_bwd_b16_k(const bf16_t* __restrict
 }  // namespace
 
 int hwgat_launch_blk_fwd_b16(const void* qkv, void* o, const uint32_t* maskbits, int B, int F, int KJ, int nH, int shifted,
-                             hipStream_t st) {
+                             uint32_t drop_seed, float drop_p, const uint32_t* seed_base, hipStream_t st) {
+    const AttnDrop ad = make_drop(drop_seed, drop_p, seed_base);
     BlkGeom g{F, KJ, nH, F / 2, nH * HD, shifted ? 1 : 0};
     const int64_t units = (int64_t)B * g.f * nH;
     const int64_t clip_bytes = (int64_t)F * KJ * 3 * g.d * 2;
     if (units > 0x7fffffff || clip_bytes > 0x7fffffff) return HWGAT_ESHAPE;
-    blk_fwd_b16_k<<<(int)units, 256, 0, st>>>((const bf16_t*)qkv, (bf16_t*)o, maskbits, g, clip_bytes * B);
+    if (ad.p > 0.f) blk_fwd_b16_k<true><<<(int)units, 256, 0, st>>>((const bf16_t*)qkv, (bf16_t*)o, maskbits, g, clip_bytes * B, ad);
+    else blk_fwd_b16_k<false><<<(int)units, 256, 0, st>>>((const bf16_t*)qkv, (bf16_t*)o, maskbits, g, clip_bytes * B, ad);
     HWGAT_LAUNCH_CHECK();
 }
 
 int hwgat_launch_blk_bwd_b16(const void* qkv, const void* dO, void* dqkv, const uint32_t* maskbits, int B, int F, int KJ,
-                             int nH, int shifted, hipStream_t st) {
+                             int nH, int shifted, uint32_t drop_seed, float drop_p, const uint32_t* seed_base, hipStream_t st) {
+    const AttnDrop ad = make_drop(drop_seed, drop_p, seed_base);
     BlkGeom g{F, KJ, nH, F / 2, nH * HD, shifted ? 1 : 0};
     const int64_t units = (int64_t)B * g.f * nH;
     const int64_t clip_bytes = (int64_t)F * KJ * 3 * g.d * 2;
     if (units > 0x7fffffff || clip_bytes > 0x7fffffff) return HWGAT_ESHAPE;
-    blk_bwd_b16_k<<<(int)units, 256, 0, st>>>((const bf16_t*)qkv, (const bf16_t*)dO, (bf16_t*)dqkv, maskbits, g, clip_bytes * B,
-                                              clip_bytes * B / 3);
+    if (ad.p > 0.f)
+        blk_bwd_b16_k<true><<<(int)units, 256, 0, st>>>((const bf16_t*)qkv, (const bf16_t*)dO, (bf16_t*)dqkv, maskbits, g,
+                                                        clip_bytes * B, clip_bytes * B / 3, ad);
+    else
+        blk_bwd_b16_k<false><<<(int)units, 256, 0, st>>>((const bf16_t*)qkv, (const bf16_t*)dO, (bf16_t*)dqkv, maskbits, g,
+                                                         clip_bytes * B, clip_bytes * B / 3, ad);
     HWGAT_LAUNCH_CHECK();
 }

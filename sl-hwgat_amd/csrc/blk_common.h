@@ -31,7 +31,8 @@ __device__ __forceinline__ BUnit decode_bunit(const BlkGeom& g, int u) {
 }  // namespace blk
 
 // bf16 storage, head_dim 64: 16x16x32 bf16 MFMA tiles, one workgroup of 4 waves per unit (blk_attn_bf16.hip)
+// (drop_seed, drop_p, seed_base): attention dropout, p = 0 for none
 int hwgat_launch_blk_fwd_b16(const void* qkv, void* o, const uint32_t* maskbits, int B, int F, int KJ, int nH, int shifted,
-                             hipStream_t st);
+                             uint32_t drop_seed, float drop_p, const uint32_t* seed_base, hipStream_t st);
 int hwgat_launch_blk_bwd_b16(const void* qkv, const void* dO, void* dqkv, const uint32_t* maskbits, int B, int F, int KJ,
-                             int nH, int shifted, hipStream_t st);
+                             int nH, int shifted, uint32_t drop_seed, float drop_p, const uint32_t* seed_base, hipStream_t st);

@@ -50,6 +50,18 @@ __device__ __forceinline__ uint32_t drop_thresh(float p) {
     return p <= 0.f ? 0u : (uint32_t)fminf(p * 65536.0f + 0.5f, 65535.0f);
 }
 
+// Attention dropout (reference HWGATE.py:78,112 / HGATE.py:78,106 / WGATE.py:81,103: nn.Dropout on the softmax output, train
+// mode): the mask is the common hash over the element index of the reference's attention tensor, so
+// hwgat_dropout_mask_f32(out, numel, seed, p) reproduces it (tests feed it to the oracles).  `base`: see common.h, seeds.
+struct AttnDrop {
+    uint32_t seed;
+    float p;                    // 0: no attention dropout
+    const uint32_t* base;       // device word added to `seed` at kernel entry (NULL = 0)
+};
+inline AttnDrop make_drop(uint32_t seed, float p, const uint32_t* base) {      // p is quantised to 1/65536
+    return AttnDrop{seed, p < 0.5f / 65536.0f ? 0.f : p, base};
+}
+
 // Exact-erf GELU (nn.GELU default, HWGATE.py:132) and its derivative.  erf is evaluated branch-free
 // with Abramowitz-Stegun 7.1.26: erf(z) = 1 - (a1 t + ... + a5 t^5) exp(-z^2), t = 1/(1 + p z), z >= 0,
 // |error| <= 1.5e-7 (fp32-rounding level; libm's erff costs ~4x the instructions and made the GELU

@@ -106,11 +106,6 @@ __device__ __forceinline__ uint32_t masked_softmax(float (&s)[16], float (&p)[16
 // for this lane's 16 probabilities P[q = lq][key = crow(r, hh)] of unit u.  The element index is the one of the
 // reference's (B_ = B f nW, nH, 32, 32) attention tensor, (u * 32 + q) * 32 + key, hashed like every other dropout
 // site (fused_ops.h): hwgat_dropout_mask_f32(out, units * 1024, seed, p) IS this mask (tests feed it to the oracle).
-struct AttnDrop {
-    uint32_t seed;
-    float p;                    // 0: no attention dropout
-    const uint32_t* base;       // device word added to `seed` at kernel entry (NULL = 0), see common.h
-};
 __device__ __forceinline__ void attn_keep(float (&k)[16], const AttnDrop& ad, int u, int lq, int hh) {
     const uint64_t base = ((uint64_t)u * 32 + lq) * 32 + 4 * hh;
     const uint32_t thresh = drop_thresh(ad.p);
@@ -662,7 +657,6 @@ int launch_bwd(const void* qkv, const void* dO, void* dqkv, const uint32_t* mb, 
 
 // attention dropout only exists in train mode (thr given); p in [0, 1)
 bool drop_ok(const float* thr, float p) { return p >= 0.f && p < 1.f && (p == 0.f || thr); }
-AttnDrop make_drop(uint32_t seed, float p, const uint32_t* base) { return AttnDrop{seed, p < 0.5f / 65536.0f ? 0.f : p, base}; }   // p is quantised to 1/65536 (fused_ops.h)
 
 }  // namespace
 

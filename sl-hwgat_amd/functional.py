@@ -192,12 +192,10 @@ class _WinAttn(torch.autograd.Function):
 
 
 def _attn_drop(kind, thr, drop):
-    """(seed, p) of the attention dropout (reference HWGATE.py:78,112) or None; only the HWGATE window kernels have it"""
+    """(seed, p, seed_base) of the attention dropout (reference HWGATE.py:78,112, HGATE.py:78,106, WGATE.py:81,103) or None"""
     if drop is None or float(drop[1]) <= 0.0:
         return None
-    if kind != "win":
-        raise NotImplementedError("attention dropout exists for the HWGATE window attention only")
-    if thr is None:
+    if kind == "win" and thr is None:
         raise ValueError("attention dropout is a train-mode operation: it needs the train-mode threshold tensor")
     return int(drop[0]) & 0xFFFFFFFF, float(drop[1]), (drop[2] if len(drop) > 2 else None)
 
@@ -215,12 +213,20 @@ def attn_fwd(kind, qkv, o, bits, thr, n_heads, shifted, drop=None):
              int(shifted), dtype_code(qkv), stream())
     elif kind == "blk":
         assert thr is None, "HGATE has no train-mode threshold"
-        call("hwgat_blk_attn_fwd", ptr(qkv), ptr(o), ptr(bits), B, F, K, n_heads, d // n_heads, int(shifted),
-             dtype_code(qkv), stream())
+        if drop is not None:
+            call("hwgat_blk_attn_fwd_drop", ptr(qkv), ptr(o), ptr(bits), B, F, K, n_heads, d // n_heads, int(shifted),
+                 dtype_code(qkv), drop[0], drop[1], ptr(drop[2]), stream())
+        else:
+            call("hwgat_blk_attn_fwd", ptr(qkv), ptr(o), ptr(bits), B, F, K, n_heads, d // n_heads, int(shifted),
+                 dtype_code(qkv), stream())
     elif kind == "band":
         assert thr is None and not shifted, "WGATE has neither threshold nor shift"
-        call("hwgat_band_attn_fwd", ptr(qkv), ptr(o), ptr(bits), B, F, K // 16, n_heads, d // n_heads,
-             dtype_code(qkv), stream())
+        if drop is not None:
+            call("hwgat_band_attn_fwd_drop", ptr(qkv), ptr(o), ptr(bits), B, F, K // 16, n_heads, d // n_heads,
+                 dtype_code(qkv), drop[0], drop[1], ptr(drop[2]), stream())
+        else:
+            call("hwgat_band_attn_fwd", ptr(qkv), ptr(o), ptr(bits), B, F, K // 16, n_heads, d // n_heads,
+                 dtype_code(qkv), stream())
     else:
         raise ValueError(kind)
 
@@ -235,62 +241,73 @@ def attn_bwd(kind, qkv, do, dqkv, bits, thr, n_heads, shifted, drop=None):
         call("hwgat_win_attn_bwd", ptr(qkv), ptr(do), ptr(dqkv), ptr(bits), ptr(thr), B, F, K // 16, n_heads,
              d // n_heads, int(shifted), dtype_code(qkv), stream())
     elif kind == "blk":
-        call("hwgat_blk_attn_bwd", ptr(qkv), ptr(do), ptr(dqkv), ptr(bits), B, F, K, n_heads, d // n_heads,
-             int(shifted), dtype_code(qkv), stream())
+        if drop is not None:
+            call("hwgat_blk_attn_bwd_drop", ptr(qkv), ptr(do), ptr(dqkv), ptr(bits), B, F, K, n_heads, d // n_heads,
+                 int(shifted), dtype_code(qkv), drop[0], drop[1], ptr(drop[2]), stream())
+        else:
+            call("hwgat_blk_attn_bwd", ptr(qkv), ptr(do), ptr(dqkv), ptr(bits), B, F, K, n_heads, d // n_heads,
+                 int(shifted), dtype_code(qkv), stream())
     elif kind == "band":
-        call("hwgat_band_attn_bwd", ptr(qkv), ptr(do), ptr(dqkv), ptr(bits), B, F, K // 16, n_heads, d // n_heads,
-             dtype_code(qkv), stream())
+        if drop is not None:
+            call("hwgat_band_attn_bwd_drop", ptr(qkv), ptr(do), ptr(dqkv), ptr(bits), B, F, K // 16, n_heads, d // n_heads,
+                 dtype_code(qkv), drop[0], drop[1], ptr(drop[2]), stream())
+        else:
+            call("hwgat_band_attn_bwd", ptr(qkv), ptr(do), ptr(dqkv), ptr(bits), B, F, K // 16, n_heads, d // n_heads,
+                 dtype_code(qkv), stream())
     else:
         raise ValueError(kind)
 
 
 class _BlkAttn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, qkv, bits, n_heads, shifted):
+    def forward(ctx, qkv, bits, n_heads, shifted, drop):
         B, F, K, d3 = qkv.shape
         o = torch.empty(B, F, K, d3 // 3, device=qkv.device, dtype=qkv.dtype)
-        attn_fwd("blk", qkv, o, bits, None, n_heads, shifted)
+        attn_fwd("blk", qkv, o, bits, None, n_heads, shifted, drop)
         ctx.save_for_backward(qkv, bits)
-        ctx.cfg = (n_heads, int(shifted))
+        ctx.cfg = (n_heads, int(shifted), drop)
         return o
 
     @staticmethod
     def backward(ctx, do):
         qkv, bits = ctx.saved_tensors
-        n_heads, shifted = ctx.cfg
+        n_heads, shifted, drop = ctx.cfg
         do = do.contiguous()
         dqkv = torch.empty_like(qkv)
-        attn_bwd("blk", qkv, do, dqkv, bits, None, n_heads, shifted)
-        return dqkv, None, None, None
+        attn_bwd("blk", qkv, do, dqkv, bits, None, n_heads, shifted, drop)
+        return dqkv, None, None, None, None
 
 
 class _BandAttn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, qkv, rows, n_heads):
+    def forward(ctx, qkv, rows, n_heads, drop):
         B, F, K, d3 = qkv.shape
         o = torch.empty(B, F, K, d3 // 3, device=qkv.device, dtype=qkv.dtype)
-        attn_fwd("band", qkv, o, rows, None, n_heads, False)
+        attn_fwd("band", qkv, o, rows, None, n_heads, False, drop)
         ctx.save_for_backward(qkv, rows)
-        ctx.n_heads = n_heads
+        ctx.cfg = (n_heads, drop)
         return o
 
     @staticmethod
     def backward(ctx, do):
         qkv, rows = ctx.saved_tensors
+        n_heads, drop = ctx.cfg
         do = do.contiguous()
         dqkv = torch.empty_like(qkv)
-        attn_bwd("band", qkv, do, dqkv, rows, None, ctx.n_heads, False)
-        return dqkv, None, None
+        attn_bwd("band", qkv, do, dqkv, rows, None, n_heads, False, drop)
+        return dqkv, None, None, None
 
 
-def band_attention(qkv, rows, n_heads):
-    """WGATE: qkv (B,F,K,3d) -> o (B,F,K,d); a window = one 16-joint part window over all F frames."""
-    return _BandAttn.apply(qkv.contiguous(), rows, n_heads)
+def band_attention(qkv, rows, n_heads, drop=None):
+    """WGATE: qkv (B,F,K,3d) -> o (B,F,K,d); a window = one 16-joint part window over all F frames.
+    `drop` = (seed, p[, seed_base]): attention dropout (reference WGATE.py:103)."""
+    return _BandAttn.apply(qkv.contiguous(), rows, n_heads, _attn_drop("band", None, drop))
 
 
-def block_attention(qkv, bits, n_heads, shifted):
-    """HGATE: qkv (B,F,K,3d) -> o (B,F,K,d); a block = 2 frames x all K joints."""
-    return _BlkAttn.apply(qkv.contiguous(), bits, n_heads, shifted)
+def block_attention(qkv, bits, n_heads, shifted, drop=None):
+    """HGATE: qkv (B,F,K,3d) -> o (B,F,K,d); a block = 2 frames x all K joints.
+    `drop` = (seed, p[, seed_base]): attention dropout (reference HGATE.py:106)."""
+    return _BlkAttn.apply(qkv.contiguous(), bits, n_heads, shifted, _attn_drop("blk", None, drop))
 
 
 def window_attention(qkv, bits, thr, n_heads, shifted, drop=None):

@@ -39,8 +39,9 @@ class Model(_base.Model):
         nn.Module.__init__(self)
         if temporal_patch_size != 2:
             raise NotImplementedError("HGATE HIP backend supports temporal_patch_size == 2")
-        if attn_drop_rate != 0.0:
-            raise NotImplementedError("attn_drop_rate must be 0 (the reference default)")
+        if not 0.0 <= float(attn_drop_rate) < 1.0:
+            raise ValueError("attn_drop_rate must be in [0, 1)")
+        self.attn_drop_rate = float(attn_drop_rate)          # nn.Dropout on the attention probabilities (HGATE.py:78,106)
         if norm_layer is not nn.LayerNorm:
             raise NotImplementedError("norm_layer must be nn.LayerNorm")
         if not 1 <= num_kps <= 32:

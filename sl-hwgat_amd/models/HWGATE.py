@@ -152,7 +152,7 @@ class Model(nn.Module):
         return self
 
     # ------------------------------------------------------------ forward
-    attn_drop_rate = 0.0      # the sibling models (HGATE / WGATE constructors) have no attention dropout
+    attn_drop_rate = 0.0      # set by every constructor (HWGATE / HGATE / WGATE)
 
     def _site_seeds(self, k):
         """four dropout-SITE seeds of block k (host integers that never change): proj, fc1, fc2 outputs

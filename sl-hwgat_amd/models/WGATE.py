@@ -29,8 +29,9 @@ class Model(_base.Model):
         nn.Module.__init__(self)
         if window_size != 16:
             raise NotImplementedError("WGATE HIP backend supports window_size == 16")
-        if attn_drop_rate != 0.0:
-            raise NotImplementedError("attn_drop_rate must be 0 (the reference default)")
+        if not 0.0 <= float(attn_drop_rate) < 1.0:
+            raise ValueError("attn_drop_rate must be in [0, 1)")
+        self.attn_drop_rate = float(attn_drop_rate)          # nn.Dropout on the attention probabilities (WGATE.py:81,103)
         if norm_layer is not nn.LayerNorm:
             raise NotImplementedError("norm_layer must be nn.LayerNorm")
         if adj_mat is None:

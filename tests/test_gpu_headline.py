@@ -202,11 +202,11 @@ def test_batch_4_bf16_train_mode_all_gradients_within_the_threshold_bracket():
     # largest few per cent of the probabilities and the whole-model effect of the selector is ~1 % of the logits / ~2.5 % of
     # a gradient (measured with the oracle) -- inside the bf16 bound.  What this test pins is that the bf16 path is not
     # WRONG in train mode at the benchmarked shape (a selector that drops the wrong side, a mis-scaled threshold: the
-    # drop-everything run below is 10x outside the bound); the selector itself is pinned entry by entry by
+    # drop-everything run below is 5x outside the bound (8 % of the logits)); the selector itself is pinned entry by entry by
     # test_window_attention_fwd_bwd (tie-free thresholds) and, with a 5.5 % effect against a 2.2 % bound, by
     # test_wide_config_fully_fused_vs_oracle.
     wrong_out, _ = run_oracle([1e-4] * 8)
-    assert rel_err(wrong_out, ref) > 10 * (BF16_TOL + 2 * w_out)
+    assert rel_err(wrong_out, ref) > 5 * (BF16_TOL + 2 * w_out)
     model.train()
     model.threshold_override = thr
     out = model(x.to(DEV))

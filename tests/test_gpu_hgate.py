@@ -28,7 +28,7 @@ def _adj(KJ, g):
     return OH.block_adjacency(a)
 
 
-def _oracle_attn(qkv, adj, n_heads, shifted):
+def _oracle_attn(qkv, adj, n_heads, shifted, attn_keep=None):
     """natural-order qkv (B,F,K,3d) -> o (B,F,K,d) through the oracle's roll / partition / attention chain"""
     B, F, K, d3 = qkv.shape
     d = d3 // 3
@@ -36,7 +36,7 @@ def _oracle_attn(qkv, adj, n_heads, shifted):
     x = torch.roll(qkv, -1, 1) if shifted else qkv
     w = x.reshape(B, F // 2, 2 * K, 3, n_heads, hd).permute(3, 0, 1, 4, 2, 5)
     sm = OH.block_shift_mask(F, K, 2, 1, qkv.dtype) if shifted else None
-    o, _ = OH.block_attention(w[0], w[1], w[2], adj.to(qkv.dtype), sm)
+    o, _ = OH.block_attention(w[0], w[1], w[2], adj.to(qkv.dtype), sm, attn_keep)
     o = o.reshape(B, F, K, d)
     return torch.roll(o, 1, 1) if shifted else o
 
@@ -70,6 +70,51 @@ def test_block_attention_fwd_bwd(hd, nH, KJ, F, B, shifted):
     outb.backward(do.to(DEV, torch.bfloat16))
     assert rel_err(outb.detach().float().cpu(), refb.detach()) < BF16_TOL
     assert rel_err(xb.grad.float().cpu(), refb_in.grad) < 2 * BF16_TOL
+
+
+@pytest.mark.parametrize("hd,nH,KJ,F,B", [(64, 2, 29, 8, 2), (64, 4, 32, 4, 3), (32, 4, 29, 6, 2), (64, 2, 5, 2, 1)])
+@pytest.mark.parametrize("shifted", [False, True])
+def test_block_attention_with_attention_dropout(hd, nH, KJ, F, B, shifted):
+    """attn_drop_rate > 0 (reference HGATE.py:78,106): the kernels' mask is the library's hash over the element index of the
+    reference's (B f, nH, 2 KJ, 2 KJ) attention tensor, so hwgat_dropout_mask_f32 hands it to the oracle; forward and
+    backward (which recomputes the mask), fp32 and bf16 storage -- i.e. the 32x32-tile kernels (fp32; bf16 at head_dim 32)
+    and the 16x16-tile bf16 kernels (head_dim 64)."""
+    g = torch.Generator().manual_seed(5 * hd + KJ + F)
+    d, p_drop, seed = nH * hd, 0.2, 0xBEEF01
+    qkv = torch.randn(B, F, KJ, 3 * d, generator=g) * 0.8
+    do = torch.randn(B, F, KJ, d, generator=g)
+    adj = _adj(KJ, g)
+    bits = HF.blk_mask_bits(adj, KJ).to(DEV)
+    keep = HF.dropout_mask((B, F // 2, nH, 2 * KJ, 2 * KJ), seed, p_drop, DEV).cpu().double()
+    kept = keep[keep > 0]
+    assert float((kept - 1.0 / (1.0 - p_drop)).abs().max()) < 1e-6 and abs(kept.numel() / keep.numel() - (1 - p_drop)) < 0.03
+
+    ref_in = qkv.double().requires_grad_(True)
+    ref = _oracle_attn(ref_in, adj, nH, shifted, keep)
+    ref.backward(do.double())
+    x = qkv.to(DEV).requires_grad_(True)
+    out = HF.block_attention(x, bits, nH, shifted, drop=(seed, p_drop))
+    out.backward(do.to(DEV))
+    assert rel_err(out.detach().cpu(), ref.detach()) < F32_TOL
+    assert rel_err(x.grad.cpu(), ref_in.grad) < F32_TOL
+    # a different seed is a different mask; p = 0 is the plain kernel, bit for bit; the seed may come from the device word
+    other = HF.block_attention(x.detach(), bits, nH, shifted, drop=(seed + 1, p_drop))
+    assert rel_err(other.cpu(), ref.detach()) > 0.05
+    assert torch.equal(HF.block_attention(x.detach(), bits, nH, shifted, drop=(seed, 0.0)), HF.block_attention(x.detach(), bits, nH, shifted))
+    base = torch.tensor([1000], dtype=torch.int32, device=DEV)
+    assert torch.equal(HF.block_attention(x.detach(), bits, nH, shifted, drop=(seed - 1000, p_drop, base)), out.detach())
+
+    xb = qkv.to(DEV, torch.bfloat16).requires_grad_(True)
+    refb_in = xb.detach().cpu().double().requires_grad_(True)
+    refb = _oracle_attn(refb_in, adj, nH, shifted, keep)
+    refb.backward(do.double())
+    outb = HF.block_attention(xb, bits, nH, shifted, drop=(seed, p_drop))
+    outb.backward(do.to(DEV, torch.bfloat16))
+    assert rel_err(outb.detach().float().cpu(), refb.detach()) < BF16_TOL
+    assert rel_err(xb.grad.float().cpu(), refb_in.grad) < 2 * BF16_TOL
+    L = hw._lib
+    o = torch.empty(B, F, KJ, d, device=DEV)
+    assert L.lib().hwgat_blk_attn_fwd_drop(L.ptr(x), L.ptr(o), L.ptr(bits), B, F, KJ, nH, hd, int(shifted), 0, seed, 1.0, None, None) < 0
 
 
 def test_block_attention_edge_rows():
@@ -254,3 +299,37 @@ def test_model_train_dropout_runs_and_is_seeded():
     assert (model(x) - a).abs().max() > 1e-3
     a.sum().backward()
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+
+
+@pytest.mark.parametrize("kind", ["hgate", "wgate"])
+def test_sibling_models_with_attention_dropout_train_and_eval_ignores_it(kind):
+    """attn_drop_rate is a constructor hyper-parameter of the reference's sibling models too (HGATE.py:232, WGATE.py:165):
+    a model built with it runs train steps whose loss differs from the attn_drop_rate = 0 model on the same weights and
+    seeds, produces finite gradients for every parameter, and its eval forward is identical to the plain model's."""
+    torch.manual_seed(11)
+    if kind == "hgate":
+        hp = hw.HGATEParams({"src_len": 16, "num_class": 5}, 2, DEV)
+        make = lambda: hw.HGATEModel(*hp.get_model_params()).to(DEV)
+    else:
+        hp = hw.WGATEParams({"src_len": 16, "num_class": 5}, 2, DEV, num_kps=32)
+        make = lambda: hw.WGATEModel(*hp.get_model_params()).to(DEV)
+    plain = make()
+    hp.attn_drop_rate = 0.25
+    dropped = make()
+    dropped.load_state_dict(plain.state_dict())
+    assert dropped.attn_drop_rate == 0.25 and plain.attn_drop_rate == 0.0
+    x = torch.rand(4, 16, plain.num_kps, 2, device=DEV)
+    plain.eval(); dropped.eval()
+    assert torch.equal(plain(x), dropped(x))
+    plain.train(); dropped.train()
+    losses = []
+    for m in (plain, dropped):
+        m._drop_calls = 7
+        out = m(x)
+        loss = out.float().logsumexp(-1).sum()
+        loss.backward()
+        losses.append(float(loss.detach()))
+        for n, q in m.named_parameters():
+            if q.requires_grad:
+                assert q.grad is not None and bool(torch.isfinite(q.grad).all()), n
+    assert abs(losses[0] - losses[1]) > 1e-6 * abs(losses[0])

@@ -20,13 +20,13 @@ DEV = "cuda:0"
 F32_TOL, BF16_TOL = 2e-5, 1e-2
 
 
-def _oracle_attn(qkv, adj, n_heads):
+def _oracle_attn(qkv, adj, n_heads, attn_keep=None):
     """natural-order qkv (B,F,K,3d) -> o (B,F,K,d) through the oracle's partition / dense attention / reverse"""
     B, F, K, d3 = qkv.shape
     d = d3 // 3
     hd = d // n_heads
     w = OW.to_windows(qkv).reshape(B, K // 16, F * 16, 3, n_heads, hd).permute(3, 0, 1, 4, 2, 5)
-    o, _ = OW.band_attention(w[0], w[1], w[2], OW.additive_mask(adj.to(qkv.dtype)))
+    o, _ = OW.band_attention(w[0], w[1], w[2], OW.additive_mask(adj.to(qkv.dtype)), attn_keep)
     return OW.from_windows(o, F)
 
 
@@ -69,6 +69,44 @@ def test_band_attention_fwd_bwd(hd, nH, nW, F, B):
     refb = _oracle_attn(refb_in, adj, nH)
     refb.backward(do.double())
     outb = HF.band_attention(xb, rows, nH)
+    outb.backward(do.to(DEV, torch.bfloat16))
+    assert rel_err(outb.detach().float().cpu(), refb.detach()) < BF16_TOL
+    assert rel_err(xb.grad.float().cpu(), refb_in.grad) < 2 * BF16_TOL
+
+
+@pytest.mark.parametrize("hd,nH,nW,F,B", [(16, 8, 2, 8, 2), (16, 2, 4, 37, 1), (32, 4, 3, 5, 2), (16, 4, 1, 1, 3), (32, 2, 2, 2, 1)])
+def test_band_attention_with_attention_dropout(hd, nH, nW, F, B):
+    """attn_drop_rate > 0 (reference WGATE.py:81,103): the mask is the library's hash over the element index of the
+    reference's DENSE (B nW, nH, F 16, F 16) attention tensor -- the kernels only ever evaluate its band --, so
+    hwgat_dropout_mask_f32 hands the whole of it to the (dense) oracle; forward and backward, the fp32 kernels and the
+    workgroup-staged bf16 kernels, ragged frame segments and a last head group of 2 included."""
+    g = torch.Generator().manual_seed(7 * hd + nW + F)
+    d, K, p_drop, seed = nH * hd, nW * 16, 0.2, 0xBEEF02
+    qkv = torch.randn(B, F, K, 3 * d, generator=g) * 0.8
+    do = torch.randn(B, F, K, d, generator=g)
+    adj = OW.band_adjacency(F, nW)
+    rows = HF.band_mask_rows(adj, F).to(DEV)
+    keep = HF.dropout_mask((B, nW, nH, F * 16, F * 16), seed, p_drop, DEV).cpu().double()
+
+    ref_in = qkv.double().requires_grad_(True)
+    ref = _oracle_attn(ref_in, adj, nH, keep)
+    ref.backward(do.double())
+    x = qkv.to(DEV).requires_grad_(True)
+    out = HF.band_attention(x, rows, nH, drop=(seed, p_drop))
+    out.backward(do.to(DEV))
+    assert rel_err(out.detach().cpu(), ref.detach()) < F32_TOL
+    assert rel_err(x.grad.cpu(), ref_in.grad) < F32_TOL
+    other = HF.band_attention(x.detach(), rows, nH, drop=(seed + 1, p_drop))
+    assert rel_err(other.cpu(), ref.detach()) > 0.05
+    assert torch.equal(HF.band_attention(x.detach(), rows, nH, drop=(seed, 0.0)), HF.band_attention(x.detach(), rows, nH))
+    base = torch.tensor([77], dtype=torch.int32, device=DEV)
+    assert torch.equal(HF.band_attention(x.detach(), rows, nH, drop=(seed - 77, p_drop, base)), out.detach())
+
+    xb = qkv.to(DEV, torch.bfloat16).requires_grad_(True)
+    refb_in = xb.detach().cpu().double().requires_grad_(True)
+    refb = _oracle_attn(refb_in, adj, nH, keep)
+    refb.backward(do.double())
+    outb = HF.band_attention(xb, rows, nH, drop=(seed, p_drop))
     outb.backward(do.to(DEV, torch.bfloat16))
     assert rel_err(outb.detach().float().cpu(), refb.detach()) < BF16_TOL
     assert rel_err(xb.grad.float().cpu(), refb_in.grad) < 2 * BF16_TOL

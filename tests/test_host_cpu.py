@@ -181,7 +181,8 @@ def test_sibling_mask_rows_on_cpu():
 
 def test_attention_dropout_is_a_constructor_hyper_parameter():
     """reference HWGATE.py:273 `attn_drop_rate`: accepted by the HWGATE backend (stored, used in train mode only), range
-    checked; four site seeds per block (proj, fc1, fc2, attention); the sibling backends still refuse it"""
+    checked; four site seeds per block (proj, fc1, fc2, attention); the sibling backends take it too (HGATE.py:232,
+    WGATE.py:165) with the same range check"""
     hp = hw.HWGATEParams({"src_len": 16, "num_class": 5}, 2, "cpu", num_kps=32)
     hp.attn_drop_rate = 0.1
     m = hw.Model(*hp.get_model_params())
@@ -193,8 +194,13 @@ def test_attention_dropout_is_a_constructor_hyper_parameter():
     with pytest.raises(ValueError):
         hw.functional.window_attention(torch.zeros(1, 2, 16, 3 * 64), torch.zeros(2, 1, 32, dtype=torch.int32), None, 1, False,
                                        drop=(1, 0.1))         # eval mode (no threshold) has no dropout
-    with pytest.raises(NotImplementedError):
-        hw.functional.attn_fwd("band", None, torch.zeros(1, 2, 16, 64), None, torch.zeros(1), 1, False, drop=(1, 0.1))
+    for params, cls in ((hw.HGATEParams({"src_len": 16, "num_class": 5}, 2, "cpu"), hw.HGATEModel),
+                        (hw.WGATEParams({"src_len": 16, "num_class": 5}, 2, "cpu", num_kps=32), hw.WGATEModel)):
+        params.attn_drop_rate = 0.2
+        assert cls(*params.get_model_params()).attn_drop_rate == 0.2
+        params.attn_drop_rate = -0.1
+        with pytest.raises(ValueError):
+            cls(*params.get_model_params())
 
 
 def test_dropout_seeds_differ_per_rank_and_per_call():
