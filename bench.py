@@ -759,8 +759,7 @@ def main():
         # HBM bytes per launch from stored rocprofv3 PMC passes (FETCH_SIZE x2 correction + WRITE_SIZE, separate passes;
         # the file named in `traffic_source`) -- only valid for the shape they were taken on
         try:
-            fname = (("r03_sibling_attn_bf16_pmc_traffic.json" if args.dtype == "bf16" else "r01k_sibling_attn_pmc_traffic.json")
-                     if (hgate or wgate) else "r03_attn_pmc_traffic.json")
+            fname = "r04_sibling_attn_pmc_traffic.json" if (hgate or wgate) else "r04_attn_pmc_traffic.json"   # both dtypes, round-4 binaries
             with open(os.path.join(ROOT, "profiles", fname)) as fh:
                 pmc = json.load(fh)
             if args.dtype == "bf16":

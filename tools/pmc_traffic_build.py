@@ -22,7 +22,7 @@ CAL_E = {"win": 64 * 128 * 80 * 128, "sibling": 64 * 128 * 64 * 128}[kind]
 
 def pick(d, subs):
     subs = (subs,) if isinstance(subs, str) else subs
-    hits = {k: v for k, v in d.items() if any(k.startswith(s) for s in subs)}
+    hits = {k: v for k, v in d.items() if any(s in k for s in subs)}
     assert len(hits) == 1, (subs, list(d))
     return next(iter(hits.items()))
 
