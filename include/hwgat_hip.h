@@ -44,7 +44,8 @@ extern "C" {
  *   2000  round 2: *_ex linears, ln_fold / ln_finalize, epilogues 5 / 6, masked-gradient producers
  *   3000  round 3: see INTEGRATION.md section 3
  *   4000  round 4: every entry point with a dropout seed takes `const uint32_t* seed_base` in front of `stream`;
- *         hwgat_seed_set / hwgat_seed_advance; hwgat_is_lab_build; hwgat_blk_attn_*_drop, hwgat_band_attn_*_drop */
+ *         hwgat_seed_set / hwgat_seed_advance; hwgat_is_lab_build; hwgat_blk_attn_*_drop, hwgat_band_attn_*_drop;
+ *         hwgat_ln_bwd_det, hwgat_linear_tn_*_det (bit-reproducible parameter gradients) */
 #define HWGAT_ABI_VERSION 4000
 int hwgat_abi_version(void);
 
@@ -118,6 +119,16 @@ int hwgat_ln_bwd_xn(const void* dy, const void* x, const float* mean, const floa
                     const float* beta, const void* dres, void* dx, float* dgamma, float* dbeta, int64_t N, int d,
                     int dtype, void* dx_masked, uint32_t mask_seed, float mask_p, void* xn,
                     const uint32_t* seed_base, void* stream);
+
+/* Bit-reproducible form of the three LayerNorm-backward entry points above (round 4, "deterministic training"): every
+ * option in one call -- beta and xn both given or both NULL; dres optional unless dx_masked or xn is given; dx_masked
+ * optional -- and dgamma / dbeta summed in a FIXED order: each block stores its column sums into its own image of `ws`
+ * (hwgat_ln_bwd_det_bytes(d) bytes, need not be zeroed) and a second pass adds the images in block order (no atomics). */
+int64_t hwgat_ln_bwd_det_bytes(int d);
+int hwgat_ln_bwd_det(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                     const float* beta, const void* dres, void* dx, float* dgamma, float* dbeta, int64_t N, int d,
+                     int dtype, void* dx_masked, uint32_t mask_seed, float mask_p, void* xn,
+                     const uint32_t* seed_base, float* ws, int64_t ws_bytes, void* stream);
 
 /* ---- a-4/a-5/a-6/a-10: fused window attention (MSA.forward, HWGATE.py:89-114)
  * over the body-part joint graph, with partition/roll/reverse as index math.
@@ -333,6 +344,21 @@ int hwgat_linear_tn_bf16(const void* A, const void* B, float* dW, float* db, int
 int64_t hwgat_linear_tn_bf16_ws_bytes(int64_t M, int N, int K);
 int hwgat_linear_tn_bf16_ws(const void* A, const void* B, float* dW, float* db, int64_t M, int N, int K,
                             float* ws, int64_t ws_bytes, void* stream);
+
+/* Bit-reproducible weight / bias gradients (round 4): the same kernels as hwgat_linear_tn_f32 / _bf16 (any prologue), but
+ * the block of M split s STORES its partial dW tile and bias gradient into image s of the caller's ZERO-FILLED workspace
+ * and one pass adds the images in split order -- no float atomics, the same bits on every run.  M % 32 == 0;
+ * ws_bytes >= hwgat_linear_tn_det_bytes(M, N, K) (0: shape not supported).  Slower than the atomic / slab forms by the
+ * workspace round trip; the reference's own single-device training is reproducible, this is the mode that matches it. */
+int64_t hwgat_linear_tn_det_bytes(int64_t M, int N, int K);
+int hwgat_linear_tn_f32_det(const float* A, const float* B, float* dW, float* db, int64_t M, int N, int K,
+                            uint32_t pro_seed, float pro_p, const float* mean, const float* rstd,
+                            const float* gamma, const float* beta, const uint32_t* seed_base, float* ws,
+                            int64_t ws_bytes, void* stream);
+int hwgat_linear_tn_bf16_det(const void* A, const void* B, float* dW, float* db, int64_t M, int N, int K,
+                             uint32_t pro_seed, float pro_p, const float* mean, const float* rstd,
+                             const float* gamma, const float* beta, const uint32_t* seed_base, float* ws,
+                             int64_t ws_bytes, void* stream);
 
 /* hwgat_linear_tn_f32 with a caller-owned workspace of hwgat_linear_tn_f32_ws_bytes(M, N, K) bytes: where the 256x256-tile
  * kernel takes the shape (N, K multiples of 256, more than one tile) the partial dW tiles of the M slices go to slabs and a

@@ -24,6 +24,11 @@ _SIGS = {
     "hwgat_abi_version": [],
     "hwgat_is_lab_build": [],
     "hwgat_seed_advance": [_P, _P],
+    "hwgat_ln_bwd_det_bytes": [_I],
+    "hwgat_ln_bwd_det": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _U, _F, _P, _P, _P, _L, _P],
+    "hwgat_linear_tn_det_bytes": [_L, _I, _I],
+    "hwgat_linear_tn_f32_det": [_P, _P, _P, _P, _L, _I, _I, _U, _F, _P, _P, _P, _P, _P, _P, _L, _P],
+    "hwgat_linear_tn_bf16_det": [_P, _P, _P, _P, _L, _I, _I, _U, _F, _P, _P, _P, _P, _P, _P, _L, _P],
     "hwgat_seed_set": [_P, _U, _U, _U, _P],
     "hwgat_debug_mfma32x32x2": [_P, _P, _P, _P],
     "hwgat_debug_mfma_peak": [_P, _I, _I, _I, _P],
@@ -112,7 +117,7 @@ def lib():
         for name, args in _SIGS.items():
             fn = getattr(handle, name)
             fn.argtypes = args
-            fn.restype = _L if name.endswith("_ws_bytes") else _I
+            fn.restype = _L if name.endswith("_bytes") else _I
         have, want = handle.hwgat_abi_version(), header_abi_version()
         if have != want:
             raise RuntimeError(f"{LIB_PATH} reports ABI {have}, include/hwgat_hip.h declares {want}: rebuild the library")

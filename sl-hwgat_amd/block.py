@@ -75,7 +75,7 @@ class _FusedBlock(torch.autograd.Function):
         # xc: the "carrier" the producing block handed over with x (or None).  It has no data (a 1-element tensor
         # expanded to x's shape); its only purpose is that THIS block's backward can return, as its gradient, the masked
         # copy of dx that the producing block needs in front of its fc2 dropout (cfg `up` = that dropout's seed).
-        bits, n_heads, shifted, p, seeds, kind, want_stats, merge_out, up, carry_out, book, deterministic, attn_p, prep, sb = cfg
+        bits, n_heads, shifted, p, seeds, kind, want_stats, merge_out, up, carry_out, book, deterministic, attn_p, prep, sb, _det_bwd = cfg
         ctx.set_materialize_grads(False)          # an unused carrier gradient arrives as None, not as a zero tensor
         B, F, K, d = x.shape
         dt = x.dtype                              # fp32, or bf16 activations with fp32 master weights
@@ -136,6 +136,7 @@ class _FusedBlock(torch.autograd.Function):
         x, thr, n1w, n1b, wqkv, wp, n2w, n2b, w1, w2, m1, r1, qkv, o, y, m2, r2, h1, u = ctx.saved_tensors
         bits, n_heads, shifted, p, seeds, kind = ctx.cfg[:6]
         up, attn_p, prep, sb = ctx.cfg[8], ctx.cfg[12], ctx.cfg[13] or {}, ctx.cfg[14]
+        det = bool(ctx.cfg[15])                    # `deterministic_backward`: fixed-order parameter gradients (functional.linear_tn / ln_backward)
         if prep and ("w2T" not in prep or prep["w2T"].dtype != x.dtype):
             prep = {}
 
@@ -173,53 +174,53 @@ class _FusedBlock(torch.autograd.Function):
         if doutm is not None and doutm.shape == dout.shape:
             # the consumer of this block's output already wrote dropmask3 * dout (hwgat_ln_bwd_masked): no hashing here
             doutm = doutm.contiguous()
-            dwq.run(lambda: HF.linear_tn(doutm, u, dw2, db2))
+            dwq.run(lambda: HF.linear_tn(doutm, u, dw2, db2, deterministic=det))
             d_h1 = HF.linear_nt(doutm, wT("w2T", w2), None, epi=HF.EPI_MUL_AUX, aux=h1)
         else:
-            dwq.run(lambda: HF.linear_tn(dout, u, dw2, db2, pro_seed=seeds[2], pro_p=p, seed_base=sb))
+            dwq.run(lambda: HF.linear_tn(dout, u, dw2, db2, pro_seed=seeds[2], pro_p=p, seed_base=sb, deterministic=det))
             d_h1 = HF.linear_nt(dout, wT("w2T", w2), None, pro=HF.PRO_DROP, pro_seed=seeds[2], pro_p=p,
                                 epi=HF.EPI_MUL_AUX, aux=h1, seed_base=sb)
         xn_path = HF.dw_wants_xn(x)               # LN(x) written by the LayerNorm backward for the dW launches (bf16, d % 256 == 0)
         if not xn_path:
-            dwq.run(lambda: HF.linear_tn(d_h1, y, dw1, db1, ln=(m2, r2, n2w, n2b)))
+            dwq.run(lambda: HF.linear_tn(d_h1, y, dw1, db1, ln=(m2, r2, n2w, n2b), deterministic=det))
         d_z = HF.linear_nt(d_h1, wT("w1T", w1), None, epi=HF.EPI_NONE)
         # ---- attention branch: y = x + drop1(o Wp^T + bp)
         if p > 0.0 and HF.MASK_ONCE >= 1 and d >= HF.MASK_ONCE_MIN_D:
             if xn_path:
-                d_y, d_ym, yn = HF.ln_backward(d_z, y, m2, r2, n2w, dout, dn2w, dn2b, mask=(seeds[0], p), beta=n2b, seed_base=sb)
-                dwq.run(lambda: HF.linear_tn(d_h1, yn, dw1, db1))
+                d_y, d_ym, yn = HF.ln_backward(d_z, y, m2, r2, n2w, dout, dn2w, dn2b, mask=(seeds[0], p), beta=n2b, seed_base=sb, deterministic=det)
+                dwq.run(lambda: HF.linear_tn(d_h1, yn, dw1, db1, deterministic=det))
             else:
-                d_y, d_ym = HF.ln_backward(d_z, y, m2, r2, n2w, dout, dn2w, dn2b, mask=(seeds[0], p), seed_base=sb)   # + shortcut; and dropmask1 * d_y
-            dwq.run(lambda: HF.linear_tn(d_ym, o, dwp, dbp))
+                d_y, d_ym = HF.ln_backward(d_z, y, m2, r2, n2w, dout, dn2w, dn2b, mask=(seeds[0], p), seed_base=sb, deterministic=det)   # + shortcut; and dropmask1 * d_y
+            dwq.run(lambda: HF.linear_tn(d_ym, o, dwp, dbp, deterministic=det))
             d_o = HF.linear_nt(d_ym, wT("wpT", wp), None, epi=HF.EPI_NONE, out=d_z)
         else:
             if xn_path:
-                d_y, yn = HF.ln_backward(d_z, y, m2, r2, n2w, dout, dn2w, dn2b, beta=n2b)
-                dwq.run(lambda: HF.linear_tn(d_h1, yn, dw1, db1))
+                d_y, yn = HF.ln_backward(d_z, y, m2, r2, n2w, dout, dn2w, dn2b, beta=n2b, deterministic=det)
+                dwq.run(lambda: HF.linear_tn(d_h1, yn, dw1, db1, deterministic=det))
             else:
-                d_y = HF.ln_backward(d_z, y, m2, r2, n2w, dout, dn2w, dn2b)          # + shortcut gradient
-            dwq.run(lambda: HF.linear_tn(d_y, o, dwp, dbp, pro_seed=seeds[0], pro_p=p, seed_base=sb))
+                d_y = HF.ln_backward(d_z, y, m2, r2, n2w, dout, dn2w, dn2b, deterministic=det)          # + shortcut gradient
+            dwq.run(lambda: HF.linear_tn(d_y, o, dwp, dbp, pro_seed=seeds[0], pro_p=p, seed_base=sb, deterministic=det))
             d_o = HF.linear_nt(d_y, wT("wpT", wp), None, pro=HF.PRO_DROP, pro_seed=seeds[0], pro_p=p,
                                epi=HF.EPI_NONE, out=d_z, seed_base=sb)
         dqkv = torch.empty_like(qkv)
         HF.attn_bwd(kind, qkv, d_o, dqkv, bits, thr, n_heads, shifted, (seeds[3], attn_p, sb) if attn_p > 0.0 else None)
         if not xn_path:
-            dwq.run(lambda: HF.linear_tn(dqkv, x, dwqkv, dbqkv, ln=(m1, r1, n1w, n1b)))
+            dwq.run(lambda: HF.linear_tn(dqkv, x, dwqkv, dbqkv, ln=(m1, r1, n1w, n1b), deterministic=det))
         d_xn = HF.linear_nt(dqkv, wT("wqkvT", wqkv), None, epi=HF.EPI_NONE, out=d_o)
         # (the first block's input comes from the parameter-free embedding: its dx is still produced because
         # dgamma / dbeta of norm1 fall out of the same LayerNorm-backward pass)
         dxm = None
         if ctx.send_up:           # the block that produced x gets dropmask3(its seed) * dx through the carrier's gradient
             if xn_path:
-                dx, dxm, xn = HF.ln_backward(d_xn, x, m1, r1, n1w, d_y, dn1w, dn1b, mask=up, beta=n1b, seed_base=sb)
+                dx, dxm, xn = HF.ln_backward(d_xn, x, m1, r1, n1w, d_y, dn1w, dn1b, mask=up, beta=n1b, seed_base=sb, deterministic=det)
             else:
-                dx, dxm = HF.ln_backward(d_xn, x, m1, r1, n1w, d_y, dn1w, dn1b, mask=up, seed_base=sb)
+                dx, dxm = HF.ln_backward(d_xn, x, m1, r1, n1w, d_y, dn1w, dn1b, mask=up, seed_base=sb, deterministic=det)
         elif xn_path:
-            dx, xn = HF.ln_backward(d_xn, x, m1, r1, n1w, d_y, dn1w, dn1b, beta=n1b)
+            dx, xn = HF.ln_backward(d_xn, x, m1, r1, n1w, d_y, dn1w, dn1b, beta=n1b, deterministic=det)
         else:
-            dx = HF.ln_backward(d_xn, x, m1, r1, n1w, d_y, dn1w, dn1b)
+            dx = HF.ln_backward(d_xn, x, m1, r1, n1w, d_y, dn1w, dn1b, deterministic=det)
         if xn_path:
-            dwq.run(lambda: HF.linear_tn(dqkv, xn, dwqkv, dbqkv))
+            dwq.run(lambda: HF.linear_tn(dqkv, xn, dwqkv, dbqkv, deterministic=det))
         if dxm is not None:
             book.register(dx, dxm)
         dwq.join()        # every temporary above stays referenced until here, so the allocator cannot recycle it early
@@ -228,7 +229,7 @@ class _FusedBlock(torch.autograd.Function):
 
 def fused_block(x, thr, blk, bits, n_heads, shifted, p, seeds, kind="win", stats=None, want_stats=False,
                 merge_out=False, return_stats=False, carrier=None, up=None, carry_out=False, return_carrier=None,
-                book=None, deterministic=False, attn_p=0.0, prep=None, seed_base=None):
+                book=None, deterministic=False, attn_p=0.0, prep=None, seed_base=None, deterministic_backward=False):
     """x (B,F,K,d) contiguous; `blk` holds norm1/attn.qkv/attn.proj/norm2/ff.fc1/ff.fc2.
     `kind`: 'win' = HWGATE part-window attention, 'blk' = HGATE block attention (thr must be None).
     `stats` = (mean, rstd) of the rows of x if the producer already has them; `want_stats`: have the fc2 epilogue produce
@@ -242,6 +243,9 @@ def fused_block(x, thr, blk, bits, n_heads, shifted, p, seeds, kind="win", stats
     `attn_p`: attention dropout rate (reference HWGATE.py:78,112; 'win' only, needs `thr` and a fourth seed, seeds[3]).
     `prep`: this block's entry of the call's functional.WeightPrep (derived weight copies made by one launch per call).
     `seed_base`: 1-element device tensor added to every site seed when a kernel runs (functional.embed), or None.
+    `deterministic_backward`: bit-reproducible parameter gradients (per-split / per-block partial images added in a fixed
+    order instead of float atomics; token counts must be multiples of 32) -- with `deterministic` a whole train step repeats
+    bit for bit, like the reference's on one device.
     `deterministic`: bit-reproducible forward (eval mode): statistics / merged store stay in the epilogue only where a
     row collects at most two atomic partials.
     Returns out, or (out, (mean, rstd) or None) with `return_stats`; with `carry_out` / `return_carrier` the carrier (or None) is appended."""
@@ -254,7 +258,7 @@ def fused_block(x, thr, blk, bits, n_heads, shifted, p, seeds, kind="win", stats
         blk.ff.fc1.weight, blk.ff.fc1.bias, blk.ff.fc2.weight, blk.ff.fc2.bias,
         (bits, n_heads, shifted, float(p), tuple(int(s) for s in seeds), kind, bool(want_stats), bool(merge_out),
          (int(up[0]), float(up[1])) if (up is not None and carrier is not None) else None, bool(carry_out),
-         book, bool(deterministic), float(attn_p), prep, seed_base))
+         book, bool(deterministic), float(attn_p), prep, seed_base, bool(deterministic_backward)))
     oc = oc if oc.numel() else None
     if return_carrier is None:
         return_carrier = bool(carry_out)

@@ -34,6 +34,15 @@ __device__ __forceinline__ uint32_t seed_base_of(const uint32_t* seed_base) { re
 #define HWGAT_RESOLVE_SEEDS2(p) do { const uint32_t sb__ = seed_base_of((p).seed_base); (p).pro_seed += sb__; (p).epi_seed += sb__; } while (0)
 #define HWGAT_RESOLVE_SEED1(p) do { (p).pro_seed += seed_base_of((p).seed_base); } while (0)
 
+// epilogue of the dW kernels: plain store into the split's image (deterministic mode) or a float atomic onto dW
+#define HWGAT_TN_ACC(det, base, idx, v) do { if (det) (base)[idx] = (v); else atomicAdd((base) + (idx), (v)); } while (0)
+
+// workspace of a deterministic dW launch: `cap` zero-filled images of N K floats at `dw`, `cap` x N floats at `db`
+struct DetWs { float* dw; float* db; int cap; };
+// out[i] += sum over the `cap` images ws[s * stride + i], s ascending (unused images are zero): gemm_f32.hip
+// (`stride` floats between images; out[i] for i < count)
+int hwgat_tn_det_reduce(const float* ws, float* out, int cap, int64_t stride, int64_t count, hipStream_t st);
+
 #define HWGAT_LAUNCH_CHECK()                          \
     do {                                              \
         hipError_t e__ = hipGetLastError();           \

@@ -466,6 +466,8 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_bf16_k(TnArgsB p) {
         __syncthreads();
         buf ^= 1;
     }
+    const bool det = p.det_dw != nullptr;                       // deterministic mode: see TnArgsB
+    float* dwo = det ? p.det_dw + (int64_t)split * p.N * p.K : p.dW;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -474,7 +476,7 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_bf16_k(TnArgsB p) {
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + wn * 64 + i * 32 + crow(r, hh);
                 const int k = k0 + wk * 64 + jj * 32 + lq;
-                atomicAdd(p.dW + (int64_t)n * p.K + k, acc[i][jj][r]);
+                HWGAT_TN_ACC(det, dwo, (int64_t)n * p.K + k, acc[i][jj][r]);
             }
     if (p.db != nullptr && k0 == 0) {
         float* red = reinterpret_cast<float*>(sm);             // [16][128] partial column sums
@@ -486,7 +488,7 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_bf16_k(TnArgsB p) {
             float s = 0.f;
 #pragma unroll
             for (int q = 0; q < 16; ++q) s += red[q * 128 + tid];
-            atomicAdd(p.db + n0 + tid, s);
+            HWGAT_TN_ACC(det, det ? p.det_db + (int64_t)split * p.N : p.db, n0 + tid, s);
         }
     }
 }
@@ -643,15 +645,16 @@ extern "C" int hwgat_linear_tn_bf16_ws(const void* A, const void* B, float* dW, 
     return hwgat_launch_tn8w_bf16(a, (hipStream_t)stream, ws);
 }
 
-extern "C" int hwgat_linear_tn_bf16(const void* A, const void* B, float* dW, float* db, int64_t M, int N, int K,
-                                    uint32_t pro_seed, float pro_p, const float* mean, const float* rstd,
-                                    const float* gamma, const float* beta, const uint32_t* seed_base, void* stream) {
+static int tn_bf16_impl(const void* A, const void* B, float* dW, float* db, int64_t M, int N, int K,
+                        uint32_t pro_seed, float pro_p, const float* mean, const float* rstd,
+                        const float* gamma, const float* beta, const uint32_t* seed_base, DetWs det, void* stream) {
     if (!A || !B || !dW || M <= 0 || N <= 0 || K <= 0) return HWGAT_EINVAL;
     if (mean && (!rstd || !gamma || !beta)) return HWGAT_EINVAL;
     if (N % 128 || K % 128) return HWGAT_ESHAPE;                 // any M
     if (pro_p < 0.f || pro_p >= 1.f) return HWGAT_EINVAL;
     const int64_t m_bulk = M / TMB * TMB;
     if (m_bulk != M) {                                          // bulk launch + one RAGGED stage for the last M % 32 rows
+        if (det.dw) return HWGAT_ESHAPE;                        // deterministic mode: whole 32-row stages only (one launch, one reduction)
         if (m_bulk) {
             const int rc = hwgat_linear_tn_bf16(A, B, dW, db, m_bulk, N, K, pro_seed, pro_p, mean, rstd, gamma, beta, seed_base, stream);
             if (rc) return rc;
@@ -681,12 +684,14 @@ extern "C" int hwgat_linear_tn_bf16(const void* A, const void* B, float* dW, flo
     static const bool no8w = [] { const char* e = lab_env("HWGAT_TN8W"); return e && e[0] == '0'; }();
     if (!no8w && hwgat_tn8w_bf16_takes(M, N, K, pro_p, mean)) {
         TnArgsB a{(const bf16_t*)A, (const bf16_t*)B, dW, db, nullptr, nullptr, nullptr, nullptr, M, N, K, 1, M, pro_seed, pro_p, 0};
+        a.det_dw = det.dw; a.det_db = det.db; a.det_cap = det.cap;
         return hwgat_launch_tn8w_bf16(a, (hipStream_t)stream);
     }
     const int t256 = (N / 256) * (K / 256);
     if (!tn_old && N % 256 == 0 && K % 256 == 0 && M % 32 == 0 && 256 % t256 == 0 && !(pro_p > 0.f && mean)) {
         TnArgsB a{(const bf16_t*)A, (const bf16_t*)B, dW, db, mean, rstd, gamma, beta, M, N, K, 1, M, pro_seed, pro_p, 0};
         a.seed_base = seed_base;
+        a.det_dw = det.dw; a.det_db = det.db; a.det_cap = det.cap;
         return hwgat_launch_tn256_bf16(a, (hipStream_t)stream);
     }
     const int n_tiles = (N / 128) * (K / 128);
@@ -709,6 +714,10 @@ extern "C" int hwgat_linear_tn_bf16(const void* A, const void* B, float* dW, flo
     TnArgsB a{(const bf16_t*)A, (const bf16_t*)B, dW, db, mean, rstd, gamma, beta, M, N, K, n_split, rows,
               pro_seed, pro_p, 0};
     a.seed_base = seed_base;
+    if (det.dw) {
+        if (n_split > det.cap) return HWGAT_ESHAPE;
+        a.det_dw = det.dw; a.det_db = det.db; a.det_cap = det.cap;
+    }
     const int grid = ((n_split + 7) / 8) * 8 * n_tiles;
     hipStream_t st = (hipStream_t)stream;
     if (pro_p > 0.f) {
@@ -719,4 +728,29 @@ extern "C" int hwgat_linear_tn_bf16(const void* A, const void* B, float* dW, flo
         else gemm_tn_bf16_k<PRO_NONE, false><<<grid, 256, 0, st>>>(a);
     }
     HWGAT_LAUNCH_CHECK();
+}
+
+extern "C" int hwgat_linear_tn_bf16(const void* A, const void* B, float* dW, float* db, int64_t M, int N, int K,
+                                    uint32_t pro_seed, float pro_p, const float* mean, const float* rstd,
+                                    const float* gamma, const float* beta, const uint32_t* seed_base, void* stream) {
+    return tn_bf16_impl(A, B, dW, db, M, N, K, pro_seed, pro_p, mean, rstd, gamma, beta, seed_base, DetWs{nullptr, nullptr, 0}, stream);
+}
+
+// Deterministic form: the same kernels, but every block stores its partial dW tile / bias gradient into its M split's
+// image of the caller's ZERO-FILLED workspace and one fixed-order pass adds the images: run-to-run identical bits.
+// ws_bytes >= hwgat_linear_tn_det_bytes(M, N, K); M % 32 == 0.
+extern "C" int hwgat_linear_tn_bf16_det(const void* A, const void* B, float* dW, float* db, int64_t M, int N, int K,
+                                        uint32_t pro_seed, float pro_p, const float* mean, const float* rstd,
+                                        const float* gamma, const float* beta, const uint32_t* seed_base, float* ws,
+                                        int64_t ws_bytes, void* stream) {
+    if (!ws || N <= 0 || K <= 0) return HWGAT_EINVAL;
+    const int64_t per = (int64_t)N * K + N;
+    const int64_t cap = ws_bytes / 4 / per;
+    if (cap < 1) return HWGAT_ESHAPE;
+    const DetWs det{ws, ws + cap * (int64_t)N * K, (int)(cap > 0x7fffffff ? 0x7fffffff : cap)};
+    int rc = tn_bf16_impl(A, B, dW, db, M, N, K, pro_seed, pro_p, mean, rstd, gamma, beta, seed_base, det, stream);
+    if (rc) return rc;
+    rc = hwgat_tn_det_reduce(det.dw, dW, det.cap, (int64_t)N * K, (int64_t)N * K, (hipStream_t)stream);
+    if (rc || !db) return rc;
+    return hwgat_tn_det_reduce(det.db, db, det.cap, N, N, (hipStream_t)stream);
 }

@@ -243,6 +243,8 @@ __global__ __launch_bounds__(256, 1) void gemm_tn256_bf16_k(TnArgsB p) {
         if constexpr (NSET >= 3) stage_body(std::integral_constant<int, 2>{}, it + 2);
     }
 
+    const bool det = p.det_dw != nullptr;                       // deterministic mode: see TnArgsB
+    float* dwo = det ? p.det_dw + (int64_t)split * p.N * p.K : p.dW;
     // D[i = n][j = k]: lane (k = lq, hh), reg r -> dW[n = crow(r,hh)][k]
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(256, 1) void gemm_tn256_bf16_k(TnArgsB p) {
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + wn * 128 + i * 32 + crow(r, hh);
                 const int k = k0 + wk * 128 + jj * 32 + lq;
-                atomicAdd(p.dW + (int64_t)n * p.K + k, acc[i][jj][r]);
+                HWGAT_TN_ACC(det, dwo, (int64_t)n * p.K + k, acc[i][jj][r]);
             }
     if (want_db) {
         float* red = reinterpret_cast<float*>(sm);              // [8][256] partial column sums
@@ -264,7 +266,7 @@ __global__ __launch_bounds__(256, 1) void gemm_tn256_bf16_k(TnArgsB p) {
             float s = 0.f;
 #pragma unroll
             for (int q = 0; q < 8; ++q) s += red[q * BT + tid];
-            atomicAdd(p.db + n0 + tid, s);
+            HWGAT_TN_ACC(det, det ? p.det_db + (int64_t)split * p.N : p.db, n0 + tid, s);
         }
     }
 }
@@ -289,6 +291,7 @@ int hwgat_launch_tn256_bf16(TnArgsB a, hipStream_t st) {
     rows = (rows + TMB - 1) / TMB * TMB;
     a.n_split = (int)((a.M + rows - 1) / rows);
     a.rows_per_split = rows;
+    if (a.det_dw && a.n_split > a.det_cap) return HWGAT_ESHAPE;
     const int grid = ((a.n_split + 7) / 8) * 8 * n_tiles;
     const bool drop = a.pro_p > 0.f, ln = a.mean != nullptr;
     if (drop && ln) return HWGAT_ESHAPE;                         // not used by the model: the 128x128 kernel takes it

@@ -203,13 +203,14 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8w_bf16_k(TnArgsB p, float* __r
 #pragma unroll
             for (int c = 0; c < 4; ++c) *reinterpret_cast<f32x4*>(slab + (a * 4 + c) * 256) = acc[a][c];
     } else {
-        float* dst = p.dW + (int64_t)(n0 + gm * 128 + fq * 4) * p.K + k0 + wk * 64 + fr;
+        const bool det = p.det_dw != nullptr;                   // deterministic mode: see TnArgsB
+        float* dst = (det ? p.det_dw + (int64_t)split * p.N * p.K : p.dW) + (int64_t)(n0 + gm * 128 + fq * 4) * p.K + k0 + wk * 64 + fr;
 #pragma unroll
         for (int a = 0; a < 8; ++a)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) atomicAdd(dst + (int64_t)(a * 16 + r) * p.K + c * 16, acc[a][c][r]);
+                for (int c = 0; c < 4; ++c) HWGAT_TN_ACC(det, dst, (int64_t)(a * 16 + r) * p.K + c * 16, acc[a][c][r]);
     }
     if (want_db) {
 #pragma unroll
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8w_bf16_k(TnArgsB p, float* __r
             float s = dbacc[e];
             s += __shfl_xor(s, 16, 64);
             s += __shfl_xor(s, 32, 64);
-            if (fq == 0) atomicAdd(p.db + n0 + gm * 128 + (e * 4 + wk) * 16 + fr, s);
+            if (fq == 0) HWGAT_TN_ACC(p.det_dw != nullptr, p.det_dw ? p.det_db + (int64_t)split * p.N : p.db, n0 + gm * 128 + (e * 4 + wk) * 16 + fr, s);
         }
     }
 }
@@ -286,6 +287,10 @@ int hwgat_launch_tn8w_bf16(TnArgsB a, hipStream_t st, float* ws) {
     int64_t rows;
     tn8w_split(a.M, n_tiles, &rows, &a.n_split);
     a.rows_per_split = rows;
+    if (a.det_dw) {                                              // deterministic mode: plain images, never the slabs
+        if (a.n_split > a.det_cap) return HWGAT_ESHAPE;
+        ws = nullptr;
+    }
     const int grid = ((a.n_split + 7) / 8) * 8 * n_tiles;
     if (ws) {
         gemm_tn8w_bf16_k<true><<<grid, 512, 0, st>>>(a, ws);

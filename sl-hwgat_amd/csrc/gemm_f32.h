@@ -52,6 +52,11 @@ struct TnArgs {
     uint32_t pro_seed; float pro_p;
     int64_t row0;          // see NtArgs
     const uint32_t* seed_base;   // device word added to the site seeds at kernel entry (NULL = 0), see common.h
+    // deterministic accumulation (hwgat_linear_tn_*_det): det_dw != NULL -> the block of M split s stores its partial dW tile
+    // PLAINLY into image s of a zero-filled workspace (det_dw + s N K) and its partial bias gradient into det_db + s N
+    // instead of adding them to dW / db with float atomics; tn_det_reduce_k then adds the images in split order.
+    // det_cap = images the workspace holds (a launcher whose split count exceeds it returns HWGAT_ESHAPE).
+    float* det_dw; float* det_db; int det_cap;
 };
 
 

@@ -461,6 +461,8 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_tn
         __syncthreads();
         buf ^= 1;
     }
+    const bool det = p.det_dw != nullptr;                       // deterministic mode: see TnArgs
+    float* dwo = det ? p.det_dw + (int64_t)split * p.N * p.K : p.dW;
     // D[i = n][j = k]: 32x32: lane (k = lq, hh), reg r -> dW[n = crow(r,hh)][k]
     //                  16x16: lane (k = lane&15, q = lane>>4), reg r -> dW[n = 4q + r][k]
 #pragma unroll
@@ -471,7 +473,7 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_tn
             for (int r = 0; r < (MF16 ? 4 : 16); ++r) {
                 const int n = n0 + wn * (TNW * 32) + i * TS + (MF16 ? 4 * lk + r : crow(r, hh));
                 const int k = k0 + wk * (TKW * 32) + jj * TS + lc;
-                atomicAdd(p.dW + (int64_t)n * p.K + k, acc[i][jj][r]);
+                HWGAT_TN_ACC(det, dwo, (int64_t)n * p.K + k, acc[i][jj][r]);
             }
     if (p.db != nullptr && k0 == 0) {                           // one k-tile column owns the bias gradient
         float* red = sm;                                        // [RPP][BT] partial column sums
@@ -482,7 +484,7 @@ __global__ __launch_bounds__(C::THREADS, C::OCC * C::THREADS / 256) void gemm_tn
             float s = 0.f;
 #pragma unroll
             for (int q = 0; q < RPP; ++q) s += red[q * BT + tid];
-            atomicAdd(p.db + n0 + tid, s);
+            HWGAT_TN_ACC(det, det ? p.det_db + (int64_t)split * p.N : p.db, n0 + tid, s);
         }
     }
 }
@@ -585,6 +587,7 @@ int launch_tn(TnArgs a, hipStream_t st) {
     rows = (rows + TM - 1) / TM * TM;
     a.n_split = (int)((a.M + rows - 1) / rows);
     a.rows_per_split = rows;
+    if (a.det_dw && a.n_split > a.det_cap) return HWGAT_ESHAPE;
     const int grid = ((a.n_split + 7) / 8) * 8 * n_tiles;
     gemm_tn_k<PRO, BLN, C, MF16, RAGGED><<<grid, C::THREADS, 0, st>>>(a);
     HWGAT_LAUNCH_CHECK();
@@ -721,19 +724,21 @@ extern "C" int hwgat_linear_tn_f32_ws(const float* A, const float* B, float* dW,
     return hwgat_linear_tn_f32(A, B, dW, db, M, N, K, pro_seed, pro_p, mean, rstd, gamma, beta, seed_base, stream);
 }
 
-extern "C" int hwgat_linear_tn_f32(const float* A, const float* B, float* dW, float* db, int64_t M, int N,
-                                   int K, uint32_t pro_seed, float pro_p, const float* mean,
-                                   const float* rstd, const float* gamma, const float* beta,
-                                   const uint32_t* seed_base, void* stream) {
+static int tn_f32_impl(const float* A, const float* B, float* dW, float* db, int64_t M, int N,
+                       int K, uint32_t pro_seed, float pro_p, const float* mean,
+                       const float* rstd, const float* gamma, const float* beta,
+                       const uint32_t* seed_base, DetWs det, void* stream) {
     if (!A || !B || !dW || M <= 0 || N <= 0 || K <= 0) return HWGAT_EINVAL;
     if (mean && (!rstd || !gamma || !beta)) return HWGAT_EINVAL;
     if (N % 128 || K % 128) return HWGAT_ESHAPE;                 // any M
     if (pro_p < 0.f || pro_p >= 1.f) return HWGAT_EINVAL;
     TnArgs a{A, B, dW, db, mean, rstd, gamma, beta, M, N, K, 0, 0, pro_seed, pro_p, 0};
     a.seed_base = seed_base;
+    a.det_dw = det.dw; a.det_db = det.db; a.det_cap = det.cap;
     hipStream_t st = (hipStream_t)stream;
     const int64_t m_bulk = M / 32 * 32;                         // rows per LDS stage; the tail gets a RAGGED launch
     if (m_bulk != M) {
+        if (det.dw) return HWGAT_ESHAPE;                        // deterministic mode: whole stages only (one launch, one reduction)
         if (m_bulk) {
             const int rc = hwgat_linear_tn_f32(A, B, dW, db, m_bulk, N, K, pro_seed, pro_p, mean, rstd, gamma, beta, seed_base, stream);
             if (rc) return rc;
@@ -757,6 +762,78 @@ extern "C" int hwgat_linear_tn_f32(const float* A, const float* B, float* dW, fl
     if (mean) TN_GO(PRO_NONE, true);
     TN_GO(PRO_NONE, false);
 #undef TN_GO
+}
+
+extern "C" int hwgat_linear_tn_f32(const float* A, const float* B, float* dW, float* db, int64_t M, int N,
+                                   int K, uint32_t pro_seed, float pro_p, const float* mean,
+                                   const float* rstd, const float* gamma, const float* beta,
+                                   const uint32_t* seed_base, void* stream) {
+    return tn_f32_impl(A, B, dW, db, M, N, K, pro_seed, pro_p, mean, rstd, gamma, beta, seed_base, DetWs{nullptr, nullptr, 0}, stream);
+}
+
+// ---- deterministic weight gradients (see TnArgs::det_dw)
+namespace {
+__global__ __launch_bounds__(256) void tn_det_reduce_k(const float* __restrict__ ws, float* __restrict__ out, int cap, int64_t stride,
+                                                       int64_t count) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    float s = 0.f;
+    int sp = 0;
+    for (; sp + 8 <= cap; sp += 8) {                           // eight loads in flight, added in split order
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = ws[(sp + j) * stride + i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += v[j];
+    }
+    for (; sp < cap; ++sp) s += ws[sp * stride + i];
+    out[i] += s;
+}
+}  // namespace
+int hwgat_tn_det_reduce(const float* ws, float* out, int cap, int64_t stride, int64_t count, hipStream_t st) {
+    tn_det_reduce_k<<<(unsigned)((count + 255) / 256), 256, 0, st>>>(ws, out, cap, stride, count);
+    HWGAT_LAUNCH_CHECK();
+}
+
+// M splits any dW kernel may choose for this shape (an upper bound over the kernels of both dtypes), + margin
+static int64_t tn_det_cap(int64_t M, int N, int K) {
+    auto gcd = [](int64_t x, int64_t y) { while (y) { int64_t t = x % y; x = y; y = t; } return x; };
+    const int64_t t128 = (int64_t)(N / 128) * (K / 128);
+    int64_t cap = 0;
+    for (int64_t slots : {512, 768, 1024}) {                    // fp32 / bf16 128x128-tile kernels (2, 3, 4 resident blocks per CU)
+        const int64_t r = t128 / gcd(t128, slots);
+        cap = cap > slots * r / t128 ? cap : slots * r / t128;
+    }
+    if (N % 256 == 0 && K % 256 == 0) {                         // 256x256-tile kernels: multiples of 8, at least 8
+        const int64_t t256 = (int64_t)(N / 256) * (K / 256), r = t256 / gcd(t256, 256);
+        const int64_t w = 256 * r / t256 > 8 ? 256 * r / t256 : 8;
+        cap = cap > w ? cap : w;
+    }
+    const int64_t by_rows = M / 32 + 1;                          // never more splits than 32-row stages
+    cap = cap < by_rows ? cap : by_rows;
+    return cap + 8;
+}
+extern "C" int64_t hwgat_linear_tn_det_bytes(int64_t M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0 || N % 128 || K % 128) return 0;
+    return tn_det_cap(M, N, K) * ((int64_t)N * K + N) * 4;
+}
+
+// Deterministic form of hwgat_linear_tn_f32 (see hwgat_linear_tn_bf16_det): zero-filled workspace of
+// hwgat_linear_tn_det_bytes(M, N, K) bytes, M % 32 == 0.
+extern "C" int hwgat_linear_tn_f32_det(const float* A, const float* B, float* dW, float* db, int64_t M, int N,
+                                       int K, uint32_t pro_seed, float pro_p, const float* mean,
+                                       const float* rstd, const float* gamma, const float* beta,
+                                       const uint32_t* seed_base, float* ws, int64_t ws_bytes, void* stream) {
+    if (!ws || N <= 0 || K <= 0) return HWGAT_EINVAL;
+    const int64_t per = (int64_t)N * K + N;
+    const int64_t cap = ws_bytes / 4 / per;
+    if (cap < 1) return HWGAT_ESHAPE;
+    const DetWs det{ws, ws + cap * (int64_t)N * K, (int)(cap > 0x7fffffff ? 0x7fffffff : cap)};
+    int rc = tn_f32_impl(A, B, dW, db, M, N, K, pro_seed, pro_p, mean, rstd, gamma, beta, seed_base, det, stream);
+    if (rc) return rc;
+    rc = hwgat_tn_det_reduce(det.dw, dW, det.cap, (int64_t)N * K, (int64_t)N * K, (hipStream_t)stream);
+    if (rc || !db) return rc;
+    return hwgat_tn_det_reduce(det.db, db, det.cap, N, N, (hipStream_t)stream);
 }
 
 extern "C" int hwgat_transpose_f32(const float* in, float* out, int R, int C, void* stream) {

@@ -173,6 +173,8 @@ __global__ __launch_bounds__(256, 1) void gemm_tn256_k(TnArgs p, float* __restri
         stage_body(P1{}, it + 1);
     }
 
+    const bool det = p.det_dw != nullptr;                       // deterministic mode: see TnArgs
+    float* dwo = det ? p.det_dw + (int64_t)split * p.N * p.K : p.dW;
     // D[i = n][j = k]: lane (k = lq, hh), reg r -> dW[n = crow(r,hh)][k]
     if constexpr (SLAB) {
         float* slab = ws + ((int64_t)split * n_tiles + tile) * 65536 + wave * 16384 + lane * 4;
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(256, 1) void gemm_tn256_k(TnArgs p, float* __restri
                 for (int r = 0; r < 16; ++r) {
                     const int n = n0 + wn * 128 + i * 32 + crow(r, hh);
                     const int k = k0 + wk * 128 + jj * 32 + lq;
-                    atomicAdd(p.dW + (int64_t)n * p.K + k, acc[i][jj][r]);
+                    HWGAT_TN_ACC(det, dwo, (int64_t)n * p.K + k, acc[i][jj][r]);
                 }
     }
     if (p.db != nullptr && k0 == 0) {
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(256, 1) void gemm_tn256_k(TnArgs p, float* __restri
         __syncthreads();
         *reinterpret_cast<f32x4*>(red + lrow * BT + lc4) = colsum;
         __syncthreads();
-        if (tid < BT) atomicAdd(p.db + n0 + tid, red[tid] + red[BT + tid] + red[2 * BT + tid] + red[3 * BT + tid]);
+        if (tid < BT) HWGAT_TN_ACC(det, det ? p.det_db + (int64_t)split * p.N : p.db, n0 + tid, red[tid] + red[BT + tid] + red[2 * BT + tid] + red[3 * BT + tid]);
     }
 }
 
@@ -269,6 +271,10 @@ int hwgat_launch_tn256(TnArgs a, hipStream_t st, float* ws, int64_t ws_floats) {
     if (a.N % BT || a.K % BT || a.M % (2 * TM)) return HWGAT_ESHAPE;     // an even number of 16-row stages per M slice
     const int n_tiles = (a.N / BT) * (a.K / BT);
     tn256_split(a.M, n_tiles, a.n_split, a.rows_per_split);
+    if (a.det_dw) {                                              // deterministic mode: plain images, never the slabs
+        if (a.n_split > a.det_cap) return HWGAT_ESHAPE;
+        ws = nullptr;
+    }
     const int grid = ((a.n_split + 7) / 8) * 8 * n_tiles;
     const bool drop = a.pro_p > 0.f, ln = a.mean != nullptr;
     if (drop && ln) return HWGAT_ESHAPE;                         // not used by the model

@@ -95,7 +95,9 @@ __global__ __launch_bounds__(256) void ln_fwd_k(const T* __restrict__ x, const f
 // XN: also write LN(x) = xhat * gamma + beta (the layer input of the Linear behind this LayerNorm) for that Linear's
 // weight-gradient launch, which then takes both operands plain (LDS-DMA, gemm_bf16_tn8w.hip) instead of normalising x in
 // its loaders: xhat is in registers here anyway, the pass is HBM-bound with idle vector units.
-template <typename T, int D, bool RES, bool MASK, bool XN = false>
+// DET: dgamma / dbeta point at a workspace of gridDim.x images of 2 D floats; block b stores its column sums plainly into
+// image b (no atomics) and hwgat_tn_det_reduce adds the images in block order: bit-reproducible parameter gradients.
+template <typename T, int D, bool RES, bool MASK, bool XN = false, bool DET = false>
 __global__ __launch_bounds__(256) void ln_bwd_k(const T* __restrict__ dy, const T* __restrict__ x,
                                                 const float* __restrict__ mean_i,
                                                 const float* __restrict__ rstd_i,
@@ -196,8 +198,15 @@ __global__ __launch_bounds__(256) void ln_bwd_k(const T* __restrict__ dy, const 
     }
     __syncthreads();
     for (int i = threadIdx.x; i < D; i += 256) {
-        atomicAdd(dgamma + i, red[0][0][i] + red[0][1][i] + red[0][2][i] + red[0][3][i]);
-        atomicAdd(dbeta + i, red[1][0][i] + red[1][1][i] + red[1][2][i] + red[1][3][i]);
+        const float sg = red[0][0][i] + red[0][1][i] + red[0][2][i] + red[0][3][i];
+        const float sb = red[1][0][i] + red[1][1][i] + red[1][2][i] + red[1][3][i];
+        if constexpr (DET) {
+            dgamma[(int64_t)blockIdx.x * (2 * D) + i] = sg;
+            dgamma[(int64_t)blockIdx.x * (2 * D) + D + i] = sb;
+        } else {
+            atomicAdd(dgamma + i, sg);
+            atomicAdd(dbeta + i, sb);
+        }
     }
 }
 
@@ -333,15 +342,17 @@ int ln_fwd_t(const void* x, const float* gm, const float* bt, void* y, float* me
 #undef GO
     HWGAT_LAUNCH_CHECK();
 }
-template <typename T, bool RES, bool MASK = false, bool XN = false>
+template <typename T, bool RES, bool MASK = false, bool XN = false, bool DET = false>
 int ln_bwd_t(const void* dy, const void* x, const float* mean, const float* rstd, const float* gm,
              const void* dres, void* dx, float* dg, float* db, int64_t N, int d, hipStream_t st,
              void* dxm = nullptr, uint32_t mseed = 0, float mp = 0.f, const float* bt = nullptr, void* xn = nullptr,
-             const uint32_t* sbase = nullptr) {
+             const uint32_t* sbase = nullptr, float* det_ws = nullptr) {
+    // DET: the kernel writes per-block images into det_ws (1024 x 2 d floats), then two fixed-order reductions
+    int grid = 0;
 #define GO(D)                                                                                                        \
-    ln_bwd_k<T, D, RES, MASK, XN><<<(ln_grid(N, RowMap<D>::RPW) < 1024 ? ln_grid(N, RowMap<D>::RPW) : 1024), 256, 0, \
-                                    st>>>((const T*)dy, (const T*)x, mean, rstd, gm, (const T*)dres, (T*)dx, dg, db, \
-                                          N, (T*)dxm, mseed, mp, bt, (T*)xn, sbase)
+    grid = ln_grid(N, RowMap<D>::RPW) < 1024 ? ln_grid(N, RowMap<D>::RPW) : 1024;                                    \
+    ln_bwd_k<T, D, RES, MASK, XN, DET><<<grid, 256, 0, st>>>((const T*)dy, (const T*)x, mean, rstd, gm, (const T*)dres, (T*)dx, \
+                                          DET ? det_ws : dg, DET ? det_ws : db, N, (T*)dxm, mseed, mp, bt, (T*)xn, sbase)
     switch (d) {
         case 128: GO(128); break;
         case 256: GO(256); break;
@@ -350,6 +361,11 @@ int ln_bwd_t(const void* dy, const void* x, const float* mean, const float* rstd
         default: return HWGAT_ESHAPE;
     }
 #undef GO
+    if constexpr (DET) {
+        int rc = hwgat_tn_det_reduce(det_ws, dg, grid, 2 * (int64_t)d, d, st);
+        if (rc) return rc;
+        return hwgat_tn_det_reduce(det_ws + d, db, grid, 2 * (int64_t)d, d, st);
+    }
     HWGAT_LAUNCH_CHECK();
 }
 inline int pool_chunks(int B, int n_tok) {
@@ -494,6 +510,37 @@ extern "C" int hwgat_lnpool_fwd_det(const void* x, float* xhat_sum, float* mean,
 #undef GO
     if (partial) lnpool_reduce_k<<<B, 256, 0, st>>>(partial, xhat_sum, ch, d);
     HWGAT_LAUNCH_CHECK();
+}
+
+// Deterministic LayerNorm backward: every option of the three entry points above in one (beta / xn: both or neither; dres
+// optional unless dx_masked or xn is given; dx_masked optional), dgamma / dbeta summed in a fixed order through `ws`
+// (hwgat_ln_bwd_det_bytes(d) bytes, need not be zeroed).
+extern "C" int64_t hwgat_ln_bwd_det_bytes(int d) { return d > 0 ? (int64_t)1024 * 2 * d * 4 : 0; }
+extern "C" int hwgat_ln_bwd_det(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                                const float* beta, const void* dres, void* dx, float* dgamma, float* dbeta, int64_t N, int d,
+                                int dtype, void* dx_masked, uint32_t mask_seed, float mask_p, void* xn,
+                                const uint32_t* seed_base, float* ws, int64_t ws_bytes, void* stream) {
+    if (!dy || !x || !mean || !rstd || !gamma || !dx || !dgamma || !dbeta || !ws || N <= 0) return HWGAT_EINVAL;
+    if ((xn != nullptr) != (beta != nullptr)) return HWGAT_EINVAL;
+    if ((dx_masked || xn) && !dres) return HWGAT_EINVAL;
+    if (dx_masked && (mask_p <= 0.f || mask_p >= 1.f)) return HWGAT_EINVAL;
+    if (ws_bytes < hwgat_ln_bwd_det_bytes(d)) return HWGAT_ESHAPE;
+    hipStream_t st = (hipStream_t)stream;
+#define GO(T)                                                                                                              \
+    if (xn) return dx_masked ? ln_bwd_t<T, true, true, true, true>(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, N, d, st, \
+                                                                   dx_masked, mask_seed, mask_p, beta, xn, seed_base, ws)  \
+                             : ln_bwd_t<T, true, false, true, true>(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, N, d, st, \
+                                                                    nullptr, 0, 0.f, beta, xn, seed_base, ws);             \
+    if (dx_masked) return ln_bwd_t<T, true, true, false, true>(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, N, d, st,    \
+                                                               dx_masked, mask_seed, mask_p, nullptr, nullptr, seed_base, ws); \
+    return dres ? ln_bwd_t<T, true, false, false, true>(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, N, d, st, nullptr, \
+                                                        0, 0.f, nullptr, nullptr, nullptr, ws)                             \
+                : ln_bwd_t<T, false, false, false, true>(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, N, d, st, nullptr, \
+                                                         0, 0.f, nullptr, nullptr, nullptr, ws)
+    if (dtype == HWGAT_F32) { GO(float); }
+    if (dtype == HWGAT_BF16) { GO(bf16_t); }
+#undef GO
+    return HWGAT_EDTYPE;
 }
 
 extern "C" int hwgat_lnpool_fwd(const void* x, float* xhat_sum, float* mean, float* rstd, int B, int n_tok, int d,

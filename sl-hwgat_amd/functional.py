@@ -609,11 +609,24 @@ def linear_nt_ln(A, W, bias, ln, *, epi=EPI_BIAS, epi_seed=0, epi_p=0.0, out=Non
     return linear_nt(A, Wc, bias, pro=PRO_LN, ln=ln, epi=epi, epi_seed=epi_seed, epi_p=epi_p, out=out, seed_base=seed_base)
 
 
-def linear_tn(A, Bm, dW, db=None, *, pro_seed=0, pro_p=0.0, ln=None, seed_base=None):
+def linear_tn(A, Bm, dW, db=None, *, pro_seed=0, pro_p=0.0, ln=None, seed_base=None, deterministic=False):
     """dW[N,K] += dropmask(A)[M,N]^T . ln(Bm)[M,K]; db[N] += colsum(dropmask(A)).
-    ln = (mean, rstd, gamma, beta) normalises Bm on the fly."""
+    ln = (mean, rstd, gamma, beta) normalises Bm on the fly.
+    `deterministic`: the bit-reproducible form (hwgat_linear_tn_*_det: per-split partial images in a zero-filled
+    workspace, added in split order; no float atomics)."""
     N, K = dW.shape
     M = A.numel() // N
+    if deterministic:
+        need = _lib.lib().hwgat_linear_tn_det_bytes(M, N, K)
+        if M % 32 or need <= 0:
+            raise NotImplementedError("deterministic weight gradients need a token count that is a multiple of 32 and "
+                                      "N, K multiples of 128")
+        mean, rstd, gamma, beta = ln if ln is not None else (None, None, None, None)
+        ws = torch.zeros(need // 4, device=A.device, dtype=torch.float32)
+        call("hwgat_linear_tn_f32_det" if A.dtype == torch.float32 else "hwgat_linear_tn_bf16_det", ptr(A), ptr(Bm), ptr(dW),
+             ptr(db), M, N, K, pro_seed & 0xFFFFFFFF, float(pro_p), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(seed_base),
+             ptr(ws), need, stream())
+        return
     if A.dtype == torch.bfloat16 and ln is None and pro_p == 0.0:
         # plain bf16 operands: M-split partial tiles through a workspace + fixed-order reduction instead of global atomics
         need = _lib.lib().hwgat_linear_tn_bf16_ws_bytes(M, N, K)
@@ -644,12 +657,23 @@ def ln_stats(x, gamma, beta):
     return mean, rstd
 
 
-def ln_backward(dy, x, mean, rstd, gamma, dres, dgamma, dbeta, mask=None, beta=None, seed_base=None):
+def ln_backward(dy, x, mean, rstd, gamma, dres, dgamma, dbeta, mask=None, beta=None, seed_base=None, deterministic=False):
     """dx = dLN(dy) (+ dres); dgamma/dbeta accumulated in place.  mask = (seed, p): also returns dx * dropout-mask
     (the gradient in front of the dropout that produced this tensor) -> (dx, dx_masked).  `beta` given: ALSO returns
-    xn = LN(x) (appended), for the weight-gradient launch of the Linear behind this LayerNorm (hwgat_ln_bwd_xn)."""
+    xn = LN(x) (appended), for the weight-gradient launch of the Linear behind this LayerNorm (hwgat_ln_bwd_xn).
+    `deterministic`: dgamma / dbeta through per-block images added in a fixed order (hwgat_ln_bwd_det)."""
     d = x.shape[-1]
     dx = torch.empty_like(x)
+    if deterministic:
+        dxm = torch.empty_like(x) if mask is not None else None
+        xn = torch.empty_like(x) if beta is not None else None
+        need = _lib.lib().hwgat_ln_bwd_det_bytes(d)
+        ws = torch.empty(need // 4, device=x.device, dtype=torch.float32)
+        call("hwgat_ln_bwd_det", ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(dres), ptr(dx), ptr(dgamma),
+             ptr(dbeta), x.numel() // d, d, dtype_code(x), ptr(dxm), (mask[0] if mask else 0) & 0xFFFFFFFF,
+             float(mask[1]) if mask else 0.0, ptr(xn), ptr(seed_base), ptr(ws), need, stream())
+        out = (dx,) + ((dxm,) if mask is not None else ()) + ((xn,) if beta is not None else ())
+        return out if len(out) > 1 else dx
     if beta is not None:
         dxm = torch.empty_like(x) if mask is not None else None
         xn = torch.empty_like(x)

@@ -134,6 +134,7 @@ class Model(nn.Module):
         self.register_buffer("_seed_state", torch.zeros(4, dtype=torch.int32), persistent=False)
         self.device_seed_counter = False                          # True: a captured train step advances the counter itself
         self.deterministic_eval = True                            # eval(): fixed-order sums, bit-reproducible logits
+        self.deterministic_train = False                          # train(): the same for the whole step (slower: no float atomics anywhere)
         if device is not None:
             self.to(device)
 
@@ -183,6 +184,14 @@ class Model(nn.Module):
             self._drop_calls += 1
             HF.seed_set(self._seed_state, self._drop_calls, torch.initial_seed(), getattr(self, "rank_salt", 0))
 
+    deterministic_train = False
+
+    def _deterministic(self):
+        """bit-reproducible arithmetic for this call: eval() by default (`deterministic_eval`); train() on request
+        (`deterministic_train = True`: fixed-order row statistics, pooled sum and parameter gradients -- the reference's
+        single-device training repeats itself bit for bit with fixed seeds, this is the mode that does the same)"""
+        return bool(self.deterministic_train if self.training else self.deterministic_eval)
+
     def block_list(self):
         """every PartAttentionBlock container in execution order (what functional.weight_prep derives the copies of)"""
         return [blk for st in self.layers for blk in st.blocks]
@@ -206,7 +215,7 @@ class Model(nn.Module):
                                   return_carrier=True, book=hand.book, deterministic=hand.deterministic,
                                   attn_p=self.attn_drop_rate if self.training else 0.0,
                                   prep=hand.prep.per_block[k] if hand.prep is not None else None,
-                                  seed_base=hand.seed_base)
+                                  seed_base=hand.seed_base, deterministic_backward=hand.deterministic and self.training)
         hand.of, hand.stats, hand.carrier, hand.up = out, st, oc, ((seeds[2], p) if oc is not None else None)
         return out
 
@@ -229,7 +238,7 @@ class Model(nn.Module):
     def forward_features(self, x):
         h = self._embed(x)
         n_blocks = sum(len(st.blocks) for st in self.layers)
-        hand = HF.HandOver(last_block=n_blocks - 1, deterministic=self.deterministic_eval and not self.training)
+        hand = HF.HandOver(last_block=n_blocks - 1, deterministic=self._deterministic())
         # every derived copy of the block weights this call needs (LayerNorm folds, bf16 copies, transposes for the backward)
         hand.prep = HF.weight_prep(self, self.block_list(), self.activation_dtype, torch.is_grad_enabled())
         hand.seed_base = self._seed_base() if self.training else None

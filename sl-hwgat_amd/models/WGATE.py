@@ -94,7 +94,7 @@ class Model(_base.Model):
 
     def forward_features(self, x):
         h = self._embed(x)
-        hand = HF.HandOver(last_block=self.depths - 1, deterministic=self.deterministic_eval and not self.training)
+        hand = HF.HandOver(last_block=self.depths - 1, deterministic=self._deterministic())
         hand.prep = HF.weight_prep(self, self.block_list(), self.activation_dtype, torch.is_grad_enabled())
         hand.seed_base = self._seed_base() if self.training else None
         for k in range(self.depths):                   # every block but the last feeds the next block's LayerNorm
