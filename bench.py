@@ -578,6 +578,9 @@ def main():
                          "headline step, but the 10-17 ms sibling-model steps are close to host-bound and a timed step "
                          "runs 1.3-2.3x longer, so the default times 2 of 20 steps")
     ap.add_argument("--eval-mode", action="store_true", help="deterministic fwd+bwd (no dropout / attention drop)")
+    ap.add_argument("--deterministic", action="store_true",
+                    help="model.deterministic_train = True: every reduction of the step in a fixed order (bit-reproducible "
+                         "training like the reference's on one device); slower, never the default headline")
     ap.add_argument("--graph", action="store_true",
                     help="capture the whole train step (seed advance + fwd + loss + bwd + AdamW) in ONE HIP graph and replay it "
                          "per step (train.GraphedTrainStep): same kernels, no per-launch host work; never the default headline")
@@ -648,6 +651,7 @@ def main():
     if args.dtype == "bf16":
         model.set_activation_dtype(torch.bfloat16)
     model.train(not args.eval_mode)
+    model.deterministic_train = bool(args.deterministic)
     dist_mod.broadcast_parameters(model)
     reducer = dist_mod.GradReducer(model.parameters(), always_reduce=use_dist) if use_dist else None
     if args.graph and (args.micro_batch or args.eval_mode or use_dist):
@@ -830,6 +834,7 @@ def main():
                                    + ("eval-mode" if args.eval_mode else "train-mode drop 0.1")
                                    + (f", micro-batch {args.micro_batch}" if args.micro_batch else "")
                                    + (", whole step replayed as one HIP graph" if args.graph else "")
+                                   + (", deterministic_train (fixed-order reductions, no float atomics)" if args.deterministic else "")
                                    + (", inputs collated from host samples every step (PCIe-inclusive, not the headline)"
                                       if args.from_host else ""),
                        "global_batch": world * c["B"], "parallelism": f"dp{world}"},
@@ -839,7 +844,8 @@ def main():
             "loss": round(loss, 4),
         }
         default_run = (args.config == 2 and args.dtype == "f32" and args.model == "hwgate" and not args.eval_mode
-                       and not args.from_host and args.batch is None and args.micro_batch is None and not args.graph)
+                       and not args.from_host and args.batch is None and args.micro_batch is None and not args.graph
+                       and not args.deterministic)
         if world == 1 and default_run and not args.no_secondary:
             # the headline's model / optimizer / saved activations go first; its numbers above are final
             del step, opt, model
