@@ -14,3 +14,4 @@ for f in sorted(glob.glob("gpurun_out/r04j/bench_*.json")):
     except Exception as e:
         print(f, "ERR", e, open(f.replace(".json", ".err")).read()[-600:])
 PY
+python tools/tn8w_cache_probe.py > $O/tn8w_cache_probe.txt 2>&1; echo "probe rc $?"; cat $O/tn8w_cache_probe.txt
