@@ -334,7 +334,9 @@ def gpu_local_cpus(index, sysfs="/sys"):
                 props = dict(ln.split(None, 1) for ln in fh.read().splitlines() if " " in ln)
             if int(props.get("simd_count", "0")) > 0:
                 gpus.append((int(props.get("domain", "0")), int(props["location_id"])))
-        except (OSError, ValueError, KeyError):
+        except OSError:
+            continue            # a node this process may not read (a GPU of the host that is not in this container's device cgroup): not ours
+        except (ValueError, KeyError):
             return None, "unreadable KFD topology"
     if not gpus:
         return None, "no KFD topology in sysfs"
