@@ -372,6 +372,15 @@ def pin_rank_to_gpu_cpus(local_rank, local_world, sysfs="/sys"):
         return {"pinned": False, "reason": where}
     peers = [r for r in range(local_world) if gpu_local_cpus(r, sysfs)[0] == mine]
     slot = peers.index(local_rank)
+    # hyperthread siblings next to each other (a node's list is "64-127,192-255": 192 is the sibling of 64), so that the
+    # ranks sharing the node get disjoint PHYSICAL cores, each with both of its threads
+    def core_key(c):
+        try:
+            with open(os.path.join(sysfs, f"devices/system/cpu/cpu{c}/topology/thread_siblings_list")) as fh:
+                return (min(_cpulist(fh.read())), c)
+        except (OSError, ValueError):
+            return (c, c)
+    mine = sorted(mine, key=core_key)
     per = len(mine) // len(peers)
     share = set(mine[slot * per:(slot + 1) * per]) & set(os.sched_getaffinity(0))
     if len(share) < 2:
