@@ -445,7 +445,13 @@ extern "C" int hwgat_blk_attn_fwd_drop(const void* qkv, void* o, const uint32_t*
         case 32: return launch_bfwd<T, 32>(qkv, o, maskbits, g, (int)units, ad, st);        \
         default: return launch_bfwd<T, 64>(qkv, o, maskbits, g, (int)units, ad, st);        \
     }
-    if (dtype == HWGAT_F32) { FWD(float) }
+    if (dtype == HWGAT_F32) {
+        // head_dim 64 (every HGATE stage): the 16x16-tile, four-waves-per-unit kernels of blk_attn_f32.hip / blk_attn_bf16.hip;
+        // the 32x32-tile form stays for head_dim 32 and as the lab A/B (HWGAT_BLK_F32=0, HWGAT_BLK_B16=0)
+        static const bool old_f32 = lab_env("HWGAT_BLK_F32") && lab_env("HWGAT_BLK_F32")[0] == '0';
+        if (hd == 64 && !old_f32) return hwgat_launch_blk_fwd_f32(qkv, o, maskbits, B, F, KJ, nH, shifted, ad.seed, ad.p, ad.base, st);
+        FWD(float)
+    }
     if (dtype == HWGAT_BF16) {
         static const bool old_b16 = lab_env("HWGAT_BLK_B16") && lab_env("HWGAT_BLK_B16")[0] == '0';     // see hwgat_blk_attn_bwd
         if (hd == 64 && !old_b16) return hwgat_launch_blk_fwd_b16(qkv, o, maskbits, B, F, KJ, nH, shifted, ad.seed, ad.p, ad.base, st);
@@ -475,7 +481,11 @@ extern "C" int hwgat_blk_attn_bwd_drop(const void* qkv, const void* dO, void* dq
         case 32: return launch_bbwd<T, 32>(qkv, dO, dqkv, maskbits, g, (int)units, ad, st);       \
         default: return launch_bbwd<T, 64>(qkv, dO, dqkv, maskbits, g, (int)units, ad, st);       \
     }
-    if (dtype == HWGAT_F32) { BWD(float) }
+    if (dtype == HWGAT_F32) {
+        static const bool old_f32 = lab_env("HWGAT_BLK_F32") && lab_env("HWGAT_BLK_F32")[0] == '0';
+        if (hd == 64 && !old_f32) return hwgat_launch_blk_bwd_f32(qkv, dO, dqkv, maskbits, B, F, KJ, nH, shifted, ad.seed, ad.p, ad.base, st);
+        BWD(float)
+    }
     if (dtype == HWGAT_BF16) {
         // head_dim 64 (every HGATE stage): the 16x16-tile, four-waves-per-unit kernel of blk_attn_bf16.hip; the 32x32-tile
         // form stays for head_dim 32 and as the lab A/B (HWGAT_BLK_B16=0)

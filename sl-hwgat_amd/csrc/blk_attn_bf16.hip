@@ -21,61 +21,12 @@
 // in slot c ^ rotl1((r >> 1) & 7), applied on the DMA's source side).  ~100 registers per wave, 48 KB of LDS per
 // workgroup: three workgroups = 12 waves per CU.
 #include <stdlib.h>
-#include "blk_common.h"
-#include "attn16_common.h"
-#include "fused_ops.h"            // the dropout hash (attention dropout, HGATE.py:78,106)
+#include "blk16_common.h"
 
 namespace {
 using namespace blk;
 
 constexpr int IMG = 64 * RB;                             // one image: 64 slot rows x 128 bytes
-constexpr float SCALE = 0.125f;                          // float(64 ** -0.5), HGATE.py:79,91
-
-// masks (HGATE.py:96-104) + the "== 0 -> -10000" fill + softmax numerators over the 64 key slots of one query; pad key slots
-// are no keys at all.  s[kt][r] = raw score of key slot 16 kt + 4g + r on entry, exp(scaled, masked score - row max) on
-// exit; returns the row sum, `nz` = bit 4 kt + r set where the logit was kept (the gradient flows).
-__device__ __forceinline__ float masked_exp64(f32x4v (&s)[4], uint32_t mb0, uint32_t mb1, int gq, int KJ, uint32_t& nz) {
-    nz = 0;
-    float m = -3.0e38f;
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int j = 16 * (kt & 1) + 4 * gq + r;
-            const bool vis = ((kt >> 1 ? mb1 : mb0) >> j) & 1u;
-            float v = vis ? s[kt][r] * SCALE : 0.f;
-            if (v == 0.f) v = -10000.f; else nz |= 1u << (4 * kt + r);          // HGATE.py:104
-            if (j >= KJ) { v = -3.0e38f; nz &= ~(1u << (4 * kt + r)); }
-            s[kt][r] = v;
-            m = __builtin_fmaxf(m, v);
-        }
-    m = xg_max(m);
-    float sum = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            s[kt][r] = __builtin_amdgcn_exp2f((s[kt][r] - m) * LOG2E);
-            sum += s[kt][r];
-        }
-    return xg_sum(sum);
-}
-
-// attention dropout: keep[kt][r] = 1/(1-p) or 0 for P[query slot][key slot 16 kt + 4g + r] of unit u = element
-// ((u * N2 + q) * N2 + key) of the reference's (B f, nH, N2, N2) attention tensor, N2 = 2 KJ, token = frame * KJ + joint
-__device__ __forceinline__ void blk_keep16(f32x4v (&k)[4], const AttnDrop& ad, int u, int q_slot, int gq, int KJ) {
-    const uint32_t thresh = drop_thresh(ad.p);
-    const float scale = 1.0f / (1.0f - ad.p);
-    const int qj = q_slot & 31;
-    const uint64_t row = ((uint64_t)u * (2 * KJ) + (q_slot >> 5) * KJ + (qj < KJ ? qj : KJ - 1)) * (2 * KJ);
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int j = 16 * (kt & 1) + 4 * gq + r;
-            k[kt][r] = j < KJ ? drop_keep(ad.seed, row + (kt >> 1) * KJ + j, thresh, scale) : 0.f;
-        }
-}
 
 // ---- stage: wave w issues DMA instructions 2w, 2w+1 (8 slot rows each) of each image: Q, K, V (and dO with NIMG = 4)
 template <int NIMG>

@@ -1,5 +1,5 @@
-// HGATE block attention: geometry and unit decoding shared by the 32x32-tile kernels (blk_attn.hip) and the bf16 backward
-// on 16x16 tiles (blk_attn_bf16.hip).  Reference: hwgat/models/HGATE.py:30-47,184-207 (block partition / roll), :84-108.
+// HGATE block attention: geometry and unit decoding shared by the 32x32-tile kernels (blk_attn.hip) and the four-wave
+// kernels on 16x16 tiles (blk_attn_bf16.hip, blk_attn_f32.hip).  Reference: hwgat/models/HGATE.py:30-47,184-207 (block partition / roll), :84-108.
 #pragma once
 #include "common.h"
 
@@ -35,4 +35,9 @@ __device__ __forceinline__ BUnit decode_bunit(const BlkGeom& g, int u) {
 int hwgat_launch_blk_fwd_b16(const void* qkv, void* o, const uint32_t* maskbits, int B, int F, int KJ, int nH, int shifted,
                              uint32_t drop_seed, float drop_p, const uint32_t* seed_base, hipStream_t st);
 int hwgat_launch_blk_bwd_b16(const void* qkv, const void* dO, void* dqkv, const uint32_t* maskbits, int B, int F, int KJ,
+                             int nH, int shifted, uint32_t drop_seed, float drop_p, const uint32_t* seed_base, hipStream_t st);
+// fp32 storage and arithmetic, head_dim 64: 16x16x4 fp32 MFMA tiles, one workgroup of 4 waves per unit (blk_attn_f32.hip)
+int hwgat_launch_blk_fwd_f32(const void* qkv, void* o, const uint32_t* maskbits, int B, int F, int KJ, int nH, int shifted,
+                             uint32_t drop_seed, float drop_p, const uint32_t* seed_base, hipStream_t st);
+int hwgat_launch_blk_bwd_f32(const void* qkv, const void* dO, void* dqkv, const uint32_t* maskbits, int B, int F, int KJ,
                              int nH, int shifted, uint32_t drop_seed, float drop_p, const uint32_t* seed_base, hipStream_t st);
