@@ -8,20 +8,23 @@
 // Here a unit (2 frames x KJ <= 32 joints = 64 token slots, one head) is shared by a workgroup of FOUR waves on
 // v_mfma_f32_16x16x4_f32 tiles, the structure of blk_attn_bf16.hip:
 //
-//   stage   Q, K, V, dO of the unit: 4 images of 64 slot rows x 256 bytes, fetched by LDS-DMA (16 bytes per lane, whole
-//           256-byte rows, no registers); pad slots (joint >= KJ) re-read joint KJ-1 and are masked out below.
+//   stage   Q, K, V, dO of the unit: 4 images of 64 slot rows x 256 bytes.  The workgroups are persistent (two or three per
+//           CU) and a wave holds the NEXT unit's rows in registers (16 bytes per lane and load, whole 256-byte rows, 64 / 48
+//           registers), fetched while the current unit is computed and written to the images when they are free: with two
+//           or three units resident per CU nothing else hides a unit's load latency (one workgroup per unit with LDS-DMA
+//           staging left the matrix pipe idle half the time: LABLOG 10.8).  Pad slots (joint >= KJ) re-read joint KJ-1
+//           and are masked out below.
 //   phase A wave w owns QUERY slots 16w .. 16w+15.  S^T = K Q^T and dP^T = V dO^T: both sides as row operands (lane (l, g)
 //           reads the 16-byte chunk 4 m + g of its row: one ds_read_b128 feeds four MFMAs; the k index of an MFMA is any
 //           four channels as long as both operands agree).  Result lane = query, 4 x 4 registers = the lane's 16 of the 64
 //           key slots.  Masks, the "== 0 -> -10000" fill (HGATE.py:104) and the softmax in registers; dS = P (dP - delta)
-//           where the logit was kept.  O^T = V^T P^T / dQ^T = K^T dS^T: the A operand of row i = channel 4 i + ct, so ONE
-//           ds_read_b128 of chunk l of a key row feeds the four channel tiles, and a lane ends up with 16 consecutive
-//           channels of its query = 64 bytes of stores.
+//           where the logit was kept.  O = P V / dQ = dS K: P (dS) straight from the registers as the A operand, and column j of
+//           the B operand of channel tile ct = channel 4 j + ct, so ONE ds_read_b128 of chunk l of a key row feeds the four
+//           channel tiles and the sixteen lanes of a result register hold one whole 256-byte row: 4 rows per store.
 //   phase B wave w owns KEY slots 16w .. 16w+15: dK^T = Q^T dS, dV^T = dO^T P, with P and dS exchanged through two
 //           [query][key] images that overlay the K and V images once every wave is through phase A.
 //
-// Every operand read is conflict-free under one XOR swizzle of the sixteen 16-byte chunks of a row, applied on the DMA's
-// source side (xrf below).  64 KB of LDS per workgroup in the backward pass (two workgroups = 8 waves per CU), 48 KB in the
+// Every operand read is conflict-free under one XOR swizzle of the sixteen 16-byte chunks of a row (xrf below).  64 KB of LDS per workgroup in the backward pass (two workgroups = 8 waves per CU), 48 KB in the
 // forward pass (three workgroups).  HBM traffic is the algorithmic 4 E s / 7 E s.
 #include <stdlib.h>
 #include "blk16_common.h"
@@ -31,6 +34,23 @@ using namespace blk;
 
 typedef __attribute__((address_space(3))) f32x4v lds_f32x4;
 typedef __attribute__((address_space(3))) float lds_f32;
+
+#ifdef HWGAT_LAB
+// lab build only: s_memtime stamps of wave 0 of every workgroup, [workgroup][unit slot < 8][10], through a pointer set with
+// hwgat_lab_blk_stamps (tools/blk_stamps.py)
+__device__ unsigned long long* g_blk_stamps = nullptr;
+#define BLK_STAMP(i)                                                                                              \
+    do {                                                                                                          \
+        if (g_blk_stamps && threadIdx.x == 0 && stamp_slot < 8)                                                   \
+            g_blk_stamps[((size_t)blockIdx.x * 8 + stamp_slot) * 10 + (i)] = __builtin_amdgcn_s_memtime();       \
+    } while (0)
+#define BLK_STAMP_NEXT() ++stamp_slot
+#define BLK_STAMP_DECL() int stamp_slot = 0
+#else
+#define BLK_STAMP(i) do {} while (0)
+#define BLK_STAMP_NEXT() do {} while (0)
+#define BLK_STAMP_DECL() do {} while (0)
+#endif
 
 constexpr int RBF = 256;                                 // bytes per slot row of an image
 constexpr int IMGF = 64 * RBF;                           // one image: 64 slot rows
@@ -58,61 +78,94 @@ __device__ __forceinline__ f32x4v col_op_f(const char* img, int row, int lr) {
     return *(const lds_f32x4*)(img + chunk_off_f(row, lr));
 }
 
-// ---- stage: wave w issues DMA instructions 4w .. 4w+3 (4 slot rows each) of each image: Q, K, V (and dO with NIMG = 4)
-template <int NIMG>
-__device__ __forceinline__ void stage_unit_f(char* sm, const float* qkv, const float* dO, const BlkGeom& g, const BUnit& un,
-                                             int64_t qkv_bytes, int64_t do_bytes, int lane, int w) {
-    const int64_t rs = 3 * (int64_t)g.d;
-    const uint32_t rs4 = (uint32_t)rs * 4, d4 = (uint32_t)g.d * 4;
-    const int64_t t0 = min(un.base[0], un.base[1]);              // (a shifted block that wraps has frame B in front of frame A)
-    const float* qb = qkv + t0 * rs + un.head * HD;
-    const int span_q = (int)min(qkv_bytes - ((const char*)qb - (const char*)qkv), (int64_t)0x7fffffff);
-    const auto rq = __builtin_amdgcn_make_buffer_rsrc((void*)qb, 0, span_q, 0x00020000);
+typedef __attribute__((address_space(3))) u32x4v lds_u32x4f;
+
+// ---- stage: wave w fetches slot rows 16w .. 16w+15 of each image (Q, K, V and, with NIMG = 4, dO): load jj covers rows
+// 16w + 4jj .. + 3, lane l the 16-byte chunk l & 15 of row l >> 4 of them
+struct LaneOffs { uint32_t q[4], g[4]; };                     // BYTE offsets of the lane's four loads inside a frame of qkv / dO
+__device__ __forceinline__ LaneOffs lane_offs(const BlkGeom& g, int lane, int w) {
+    LaneOffs lo;
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
-        const int ins = 4 * w + jj;                              // slot rows 4 ins .. 4 ins + 3
-        const int row = 4 * ins + (lane >> 4), cp = lane & 15;
-        const int joint = min(row & 31, g.KJ - 1);               // pad slots re-read the last joint (finite data, masked later)
-        const uint32_t frame_rel = (uint32_t)((ins >> 3 ? un.base[1] : un.base[0]) - t0);
-        const uint32_t src = (uint32_t)(cp ^ xrf(row)) << 4;
-        const int vq = (int)((frame_rel + joint) * rs4 + src);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (lds_void)(sm + ins * 1024), 16, vq, 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (lds_void)(sm + IMGF + ins * 1024), 16, vq, (int)d4, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (lds_void)(sm + 2 * IMGF + ins * 1024), 16, vq, (int)(2 * d4), 0, 0);
-        if constexpr (NIMG == 4) {
-            const float* gb = dO + t0 * (int64_t)g.d + un.head * HD;
-            const int span_g = (int)min(do_bytes - ((const char*)gb - (const char*)dO), (int64_t)0x7fffffff);
-            const auto rg = __builtin_amdgcn_make_buffer_rsrc((void*)gb, 0, span_g, 0x00020000);
-            const int vg = (int)((frame_rel + joint) * d4 + src);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_void)(sm + 3 * IMGF + ins * 1024), 16, vg, 0, 0, 0);
-        }
+        const int row = 16 * w + 4 * jj + (lane >> 4);
+        const uint32_t joint = min(row & 31, g.KJ - 1);          // pad slots re-read the last joint (finite data, masked later)
+        lo.q[jj] = (joint * 3u * g.d + (lane & 15) * 4) * 4;
+        lo.g[jj] = (joint * (uint32_t)g.d + (lane & 15) * 4) * 4;
+    }
+    return lo;
+}
+// wave-uniform base + 32-bit lane offset: the scalar-base form of global_load (no 64-bit address registers per load)
+// (the empty asm keeps the 32 -> 64 bit extension of the offset in the block of the load: hoisted out of the loop, instruction
+//  selection no longer sees it and falls back to 64-bit address registers, which it builds in the destination registers --
+//  behind a wait for every outstanding store)
+__device__ __forceinline__ u32x4v ld16(const float* base, uint32_t byte_off) {
+    asm volatile("" : "+v"(byte_off));
+    return *reinterpret_cast<const u32x4v*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+// load jj of the four (the NIMG images' slot rows 16w + 4jj .. + 3)
+template <int NIMG>
+__device__ __forceinline__ void fetch_part(u32x4v (&r)[NIMG][4], int jj, const float* qkv, const float* dO, const BlkGeom& g,
+                                           const BUnit& un, const LaneOffs& lo, int w) {
+    const int64_t base = w >> 1 ? un.base[1] : un.base[0];
+    const float* qb = qkv + base * 3 * g.d + un.head * HD;
+    r[0][jj] = ld16(qb, lo.q[jj]);
+    r[1][jj] = ld16(qb + g.d, lo.q[jj]);
+    r[2][jj] = ld16(qb + 2 * g.d, lo.q[jj]);
+    if constexpr (NIMG == 4) r[3][jj] = ld16(dO + base * g.d + un.head * HD, lo.g[jj]);
+}
+template <int NIMG>
+__device__ __forceinline__ void fetch_unit(u32x4v (&r)[NIMG][4], const float* qkv, const float* dO, const BlkGeom& g,
+                                           const BUnit& un, const LaneOffs& lo, int w) {
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) fetch_part<NIMG>(r, jj, qkv, dO, g, un, lo, w);
+}
+template <int NIMG>
+__device__ __forceinline__ void put_unit(char* sm, const u32x4v (&r)[NIMG][4], int lane, int w) {
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const uint32_t off = chunk_off_f(16 * w + 4 * jj + (lane >> 4), lane & 15);
+#pragma unroll
+        for (int im = 0; im < NIMG; ++im) *(lds_u32x4f*)(sm + im * IMGF + off) = r[im][jj];
     }
 }
 
-// X^T (+)= sum over the 64 key (query) slots of  img[slot][channel]^T  b[slot]:  acc[ct][r] = channel 16 g + 4 r + ct of the
-// lane's query (key), where b[kt][r] is the lane's value for slot 16 kt + 4 g + r (the result layout of phase A)
-__device__ __forceinline__ void colT_times_regs(const char* img, const f32x4v (&b)[4], int lr, int gq, f32x4v (&acc)[4]) {
+// The workgroups that share a CU run the same code on the same schedule: started together they stay in step, want the matrix
+// pipe in the same phases and leave it idle in the same phases (stamps: LABLOG 10.8).  The grid is `per_cu` waves of 256
+// workgroups; workgroup i of wave k = i / 256 starts k * skew * 64 cycles late, so that the residents of a CU sit in different
+// phases of a unit.
+__device__ __forceinline__ void start_skew(int skew, int per_cu) {
+    const int k = blockIdx.x / 256;
+    for (int i = 0; i < k * (skew & 0xffff); ++i) __builtin_amdgcn_s_sleep(1);
+}
+
+// X (+)= sum over the 64 key (query) slots of  b[slot] img[slot][channel]:  acc[ct][r] = channel 4 l + ct of row 4 g + r of the
+// wave's 16 queries (keys), where b[kt][r] is the lane's value for slot 16 kt + 4 g + r (the result layout of phase A, here the A
+// operand: row i of the product = query l) and one ds_read_b128 of chunk l of a slot row feeds the four channel tiles (the B
+// operand: column j of tile ct = channel 4 j + ct).  The sixteen lanes l of a register then hold one whole 256-byte row.
+__device__ __forceinline__ void regs_times_col(const char* img, const f32x4v (&b)[4], int lr, int gq, f32x4v (&acc)[4]) {
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const f32x4v a = col_op_f(img, 16 * kt + 4 * gq + r, lr);
+            const f32x4v v = col_op_f(img, 16 * kt + 4 * gq + r, lr);
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) acc[ct] = mfma4(a[ct], b[kt][r], acc[ct]);
+            for (int ct = 0; ct < 4; ++ct) acc[ct] = mfma4(b[kt][r], v[ct], acc[ct]);
         }
 }
-// the lane's 16 consecutive channels 16 g .. 16 g + 15 (scaled) to p[0..15]
-__device__ __forceinline__ void store16(float* p, const f32x4v (&acc)[4], float scale) {
+// rows 4 g + r < n_real of the wave's 16-row tile (scaled): 16 bytes per lane, 4 whole rows per store instruction (lanes that
+// each own 16 channels of one row -- 64 scattered 16-byte pieces per instruction -- cost the backward pass 19 %: LABLOG 10.8)
+__device__ __forceinline__ void store_rows(float* tile, int64_t row_stride, const f32x4v (&acc)[4], float scale, int gq, int n_real) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-        *reinterpret_cast<f32x4v*>(p + 4 * j) = f32x4v{acc[0][j], acc[1][j], acc[2][j], acc[3][j]} * scale;
+    for (int r = 0; r < 4; ++r)
+        if (4 * gq + r < n_real)
+            *reinterpret_cast<f32x4v*>(tile + (4 * gq + r) * row_stride) = f32x4v{acc[0][r], acc[1][r], acc[2][r], acc[3][r]} * scale;
 }
 
 // =============================================================== forward
 template <bool ADROP>
 __global__ __launch_bounds__(256, 3) void blk_fwd_f32_k(const float* __restrict__ qkv, float* __restrict__ o,
-                                                        const uint32_t* __restrict__ maskbits, BlkGeom g, int64_t qkv_bytes,
-                                                        AttnDrop ad) {
+                                                        const uint32_t* __restrict__ maskbits, BlkGeom g, int n_units,
+                                                        AttnDrop ad, int skew) {
     if constexpr (ADROP) ad.seed += seed_base_of(ad.base);
     __shared__ __attribute__((aligned(1024))) char sm[3 * IMGF];  // Q | K | V
     const char* Qt = sm;
@@ -120,49 +173,87 @@ __global__ __launch_bounds__(256, 3) void blk_fwd_f32_k(const float* __restrict_
     const char* Vt = sm + 2 * IMGF;
     const int lane = threadIdx.x & 63, lr = lane & 15, gq = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const BUnit un = decode_bunit(g, blockIdx.x);
-    stage_unit_f<3>(sm, qkv, nullptr, g, un, qkv_bytes, 0, lane, w);
-    const int slot = 16 * w + lr;
-    const bool real = (slot & 31) < g.KJ;
-    const int64_t tok = (w >> 1 ? un.base[1] : un.base[0]) + min(slot & 31, g.KJ - 1);
-    const uint32_t mb0 = maskbits[(un.mrow + slot) * 2], mb1 = maskbits[(un.mrow + slot) * 2 + 1];
-    wait_vm0();
-    wg_barrier();
-
-    f32x4v s[4];
+    const int slot = 16 * w + lr;                                // this lane's query slot
+    const int n_real = min(max(g.KJ - 16 * (w & 1), 0), 16);     // rows of the wave's 16-slot tile that are joints
+    int u = blockIdx.x;                                          // (the grid has at most n_units workgroups)
+    BUnit un = decode_bunit(g, u);
+    const LaneOffs lo = lane_offs(g, lane, w);
+    u32x4v nx[3][4];
+    fetch_unit<3>(nx, qkv, nullptr, g, un, lo, w);
+    start_skew(skew, 3);
+    // the query's mask words, both variants (plain / last block of a shifted layer): no loads besides the prefetch in the loop
+    const uint32_t mp0 = maskbits[slot * 2], mp1 = maskbits[slot * 2 + 1], ml0 = maskbits[(64 + slot) * 2], ml1 = maskbits[(64 + slot) * 2 + 1];
+    // the unit in the images (tok0, head, ucur, mb0, mb1) and the one in flight (un, nx)
+    int64_t tok0;                                                // first token of the wave's 16-slot tile
+    int head, ucur;
+    uint32_t mb0, mb1;
+    bool more;
+    auto advance = [&]() {
+        tok0 = (w >> 1 ? un.base[1] : un.base[0]) + 16 * (w & 1);
+        head = un.head;
+        ucur = u;
+        mb0 = un.mrow ? ml0 : mp0;
+        mb1 = un.mrow ? ml1 : mp1;
+        u += gridDim.x;
+        more = u < n_units;
+        if (more) un = decode_bunit(g, u);
+    };
+    put_unit<3>(sm, nx, lane, w);
+    advance();
+    wait_lds_barrier();
+    for (;;) {
+        f32x4v s[4];
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) s[kt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < 4; ++kt) s[kt] = f32x4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const f32x4v q = row_op_f(Qt, slot, m, gq);
-        f32x4v k[4];
+        for (int m = 0; m < 4; ++m) {
+            // a quarter of the next unit's rows per step: sixteen loads in one burst from every wave of the CU fill the
+            // address queue, and a wave that cannot issue its load issues no MFMA either
+            if (more) fetch_part<3>(nx, m, qkv, nullptr, g, un, lo, w);
+            const f32x4v q = row_op_f(Qt, slot, m, gq);
+            f32x4v k[4];
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) k[kt] = row_op_f(Kt, 16 * kt + lr, m, gq);
+            for (int kt = 0; kt < 4; ++kt) k[kt] = row_op_f(Kt, 16 * kt + lr, m, gq);
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+            for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) s[kt] = mfma4(k[kt][e], q[e], s[kt]);      // S[q][key 16 kt + 4g + r]
+                for (int kt = 0; kt < 4; ++kt) s[kt] = mfma4(k[kt][e], q[e], s[kt]);      // S[q][key 16 kt + 4g + r]
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        uint32_t nz;
+        const float inv = 1.0f / masked_exp64(s, mb0, mb1, gq, g.KJ, nz);
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) s[kt] *= inv;             // HGATE.py:105
+        if constexpr (ADROP) {                                   // HGATE.py:106
+            f32x4v keep[4];
+            blk_keep16(keep, ad, ucur, slot, gq, g.KJ);
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) s[kt] *= keep[kt];
+        }
+        f32x4v acc[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        regs_times_col(Vt, s, lr, gq, acc);                     // (products outside any lane-dependent branch: MFMAs want all lanes)
+        // the next unit's rows go to the images BEFORE this unit's stores are issued: waiting for those loads (vmcnt counts in
+        // order) then does not wait for the stores, which a wait at the top of the loop would (stamps: 18 % of a unit)
+        float* otile = o + tok0 * (int64_t)g.d + head * HD + 4 * lr;
+        if (!more) {
+            store_rows(otile, g.d, acc, 1.0f, gq, n_real);
+            break;
+        }
+        wait_lds_barrier();                                      // every wave is through with the images
+        put_unit<3>(sm, nx, lane, w);
+        advance();
+        store_rows(otile, g.d, acc, 1.0f, gq, n_real);
+        wait_lds_barrier();
     }
-    uint32_t nz;
-    const float inv = 1.0f / masked_exp64(s, mb0, mb1, gq, g.KJ, nz);
-    if constexpr (ADROP) {                                       // HGATE.py:106 (on the numerators: 1 / row sum is applied to O)
-        f32x4v keep[4];
-        blk_keep16(keep, ad, blockIdx.x, slot, gq, g.KJ);
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) s[kt] *= keep[kt];
-    }
-    f32x4v acc[4];
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4v{0.f, 0.f, 0.f, 0.f};
-    colT_times_regs(Vt, s, lr, gq, acc);                        // (products outside any lane-dependent branch: MFMAs want all lanes)
-    if (real) store16(o + tok * (int64_t)g.d + un.head * HD + 16 * gq, acc, inv);
 }
 
 // =============================================================== backward
 template <bool ADROP>
 __global__ __launch_bounds__(256, 2) void blk_bwd_f32_k(const float* __restrict__ qkv, const float* __restrict__ dO,
                                                         float* __restrict__ dqkv, const uint32_t* __restrict__ maskbits,
-                                                        BlkGeom g, int64_t qkv_bytes, int64_t do_bytes, AttnDrop ad) {
+                                                        BlkGeom g, int n_units, AttnDrop ad, int skew) {
     if constexpr (ADROP) ad.seed += seed_base_of(ad.base);
     __shared__ __attribute__((aligned(1024))) char sm[4 * IMGF];  // Q | K (then dS) | V (then P) | dO
     char* Qt = sm;
@@ -173,98 +264,149 @@ __global__ __launch_bounds__(256, 2) void blk_bwd_f32_k(const float* __restrict_
     char* Pt = Vt;
     const int lane = threadIdx.x & 63, lr = lane & 15, gq = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const BUnit un = decode_bunit(g, blockIdx.x);
     const int64_t rs = 3 * (int64_t)g.d;                         // qkv row stride (elements)
-
-    stage_unit_f<4>(sm, qkv, dO, g, un, qkv_bytes, do_bytes, lane, w);
-    // this lane's query slot in phase A / key slot in phase B, and the mask words of the query
-    const int slot = 16 * w + lr;
+    const int slot = 16 * w + lr;                                // this lane's query slot in phase A / key slot in phase B
     const bool real = (slot & 31) < g.KJ;
-    const int64_t tok = (w >> 1 ? un.base[1] : un.base[0]) + min(slot & 31, g.KJ - 1);
-    const uint32_t mb0 = maskbits[(un.mrow + slot) * 2], mb1 = maskbits[(un.mrow + slot) * 2 + 1];
-    wait_vm0();
-    wg_barrier();
+    int n_real = min(max(g.KJ - 16 * (w & 1), 0), 16);           // rows of the wave's 16-slot tile that are joints
+#ifdef HWGAT_LAB
+    if (skew & 0x10000) n_real = 0;                              // lab ablation: no stores
+    const bool no_fetch = skew & 0x20000;                        // lab ablation: the first unit's rows for every unit
+    skew &= 0xffff;
+#endif
+    int u = blockIdx.x;                                          // (the grid has at most n_units workgroups)
+    BUnit un = decode_bunit(g, u);
+    const LaneOffs lo = lane_offs(g, lane, w);
+    u32x4v nx[4][4];
+    fetch_unit<4>(nx, qkv, dO, g, un, lo, w);
+    start_skew(skew, 2);
+    // the query's mask words, both variants (plain / last block of a shifted layer): no loads besides the prefetch in the loop
+    const uint32_t mp0 = maskbits[slot * 2], mp1 = maskbits[slot * 2 + 1], ml0 = maskbits[(64 + slot) * 2], ml1 = maskbits[(64 + slot) * 2 + 1];
+    // the unit in the images (tok0, head, ucur, mb0, mb1: the mask words of the query) and the one in flight (un, nx)
+    int64_t tok0;                                                // first token of the wave's 16-slot tile
+    int head, ucur;
+    uint32_t mb0, mb1;
+    bool more;
+    auto advance = [&]() {
+        tok0 = (w >> 1 ? un.base[1] : un.base[0]) + 16 * (w & 1);
+        head = un.head;
+        ucur = u;
+        mb0 = un.mrow ? ml0 : mp0;
+        mb1 = un.mrow ? ml1 : mp1;
+        u += gridDim.x;
+        more = u < n_units;
+        if (more) un = decode_bunit(g, u);
+    };
+    BLK_STAMP_DECL();
+    put_unit<4>(sm, nx, lane, w);
+    advance();
+    wait_lds_barrier();
+    for (;;) {
+        BLK_STAMP(2);
 
-    // ================================================= phase A: query slot `slot`
-    f32x4v s[4], dp[4];
+        // ================================================= phase A: query slot `slot`
+        f32x4v s[4], dp[4];
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) { s[kt] = f32x4v{0.f, 0.f, 0.f, 0.f}; dp[kt] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
+        for (int kt = 0; kt < 4; ++kt) { s[kt] = f32x4v{0.f, 0.f, 0.f, 0.f}; dp[kt] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const f32x4v q = row_op_f(Qt, slot, m, gq), gd = row_op_f(Gt, slot, m, gq);
-        f32x4v k[4], v[4];
+        for (int m = 0; m < 4; ++m) {
+            // a quarter of the next unit's rows per step: sixteen loads in one burst from every wave of the CU fill the
+            // address queue, and a wave that cannot issue its load issues no MFMA either
+#ifdef HWGAT_LAB
+            if (!no_fetch)
+#endif
+            if (more) fetch_part<4>(nx, m, qkv, dO, g, un, lo, w);
+            const f32x4v q = row_op_f(Qt, slot, m, gq), gd = row_op_f(Gt, slot, m, gq);
+            f32x4v k[4], v[4];
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) { k[kt] = row_op_f(Kt, 16 * kt + lr, m, gq); v[kt] = row_op_f(Vt, 16 * kt + lr, m, gq); }
+            for (int kt = 0; kt < 4; ++kt) { k[kt] = row_op_f(Kt, 16 * kt + lr, m, gq); v[kt] = row_op_f(Vt, 16 * kt + lr, m, gq); }
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+            for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-                s[kt] = mfma4(k[kt][e], q[e], s[kt]);                            // S[q][key 16 kt + 4g + r]
-                dp[kt] = mfma4(v[kt][e], gd[e], dp[kt]);                         // dP[q][key]
-            }
-    }
-    uint32_t nz;
-    const float sum = masked_exp64(s, mb0, mb1, gq, g.KJ, nz);
-    const float inv = real ? 1.0f / sum : 0.f;                                   // pad query slots: P = dS = 0
-    // attention dropout: A = D o P went into O = A V, so dP = D o dA (dA = dO V^T, in `dp`) and dV = A^T dO; mask recomputed
-    f32x4v keep[ADROP ? 4 : 1];
-    if constexpr (ADROP) blk_keep16(keep, ad, blockIdx.x, slot, gq, g.KJ);
-    float delta = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-        s[kt] *= inv;                                                            // P (HGATE.py:105)
-        if constexpr (ADROP) dp[kt] *= keep[kt];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) delta = __builtin_fmaf(s[kt][r], dp[kt][r], delta);
-    }
-    delta = xg_sum(delta);
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dp[kt][r] = ((nz >> (4 * kt + r)) & 1u) ? s[kt][r] * (dp[kt][r] - delta) : 0.f;   // dS
-        if constexpr (ADROP) s[kt] *= keep[kt];                                  // the P image feeds dV only: A = D o P
-    }
-    // dQ^T[c][q] = scale * sum_key K[key][c] dS[q][key]
-    {
-        f32x4v acc[4];
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4v{0.f, 0.f, 0.f, 0.f};
-        colT_times_regs(Kt, dp, lr, gq, acc);
-        if (real) store16(dqkv + tok * rs + un.head * HD + 16 * gq, acc, SCALE);
-    }
-    wait_lds_barrier();                                          // every wave is through with the K and V images
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {                             // [query][key] images: keys 16 kt + 4g .. + 3 = chunk 4 kt + g
-        *(lds_f32x4*)(Pt + chunk_off_f(slot, 4 * kt + gq)) = s[kt];
-        *(lds_f32x4*)(Dt + chunk_off_f(slot, 4 * kt + gq)) = dp[kt];
-    }
-    wait_lds_barrier();                                          // P, dS of all four query groups are in the images
-
-    // ================================================= phase B: key slot `slot`
-    {
-        f32x4v dk[4], dv[4];
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) { dk[ct] = f32x4v{0.f, 0.f, 0.f, 0.f}; dv[ct] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
-        const int kc = 4 * w + (lr >> 2), kb = (lr & 3) * 4;    // this lane's key column of the [query][key] images
-#pragma unroll
-        for (int qt = 0; qt < 4; ++qt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int qrow = 16 * qt + 4 * gq + r;
-                const f32x4v qa = col_op_f(Qt, qrow, lr), ga = col_op_f(Gt, qrow, lr);
-                const float dsb = *(const lds_f32*)(Dt + chunk_off_f(qrow, kc) + kb);
-                const float pb = *(const lds_f32*)(Pt + chunk_off_f(qrow, kc) + kb);
-#pragma unroll
-                for (int ct = 0; ct < 4; ++ct) {
-                    dk[ct] = mfma4(qa[ct], dsb, dk[ct]);                         // dK[key][c] += sum_q dS[q][key] Q[q][c]
-                    dv[ct] = mfma4(ga[ct], pb, dv[ct]);                          // dV[key][c] += sum_q P[q][key] dO[q][c]
+                for (int kt = 0; kt < 4; ++kt) {
+                    s[kt] = mfma4(k[kt][e], q[e], s[kt]);                        // S[q][key 16 kt + 4g + r]
+                    dp[kt] = mfma4(v[kt][e], gd[e], dp[kt]);                     // dP[q][key]
                 }
-            }
-        if (real) {
-            float* row = dqkv + tok * rs + un.head * HD + 16 * gq;
-            store16(row + g.d, dk, SCALE);
-            store16(row + 2 * g.d, dv, 1.0f);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        BLK_STAMP(3);
+        uint32_t nz;
+        const float sum = masked_exp64(s, mb0, mb1, gq, g.KJ, nz);
+        const float inv = real ? 1.0f / sum : 0.f;                               // pad query slots: P = dS = 0
+        // attention dropout: A = D o P went into O = A V, so dP = D o dA (dA = dO V^T, in `dp`) and dV = A^T dO; mask recomputed
+        f32x4v keep[ADROP ? 4 : 1];
+        if constexpr (ADROP) blk_keep16(keep, ad, ucur, slot, gq, g.KJ);
+        float delta = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            s[kt] *= inv;                                                        // P (HGATE.py:105)
+            if constexpr (ADROP) dp[kt] *= keep[kt];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) delta = __builtin_fmaf(s[kt][r], dp[kt][r], delta);
+        }
+        delta = xg_sum(delta);
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dp[kt][r] = ((nz >> (4 * kt + r)) & 1u) ? s[kt][r] * (dp[kt][r] - delta) : 0.f;   // dS
+            if constexpr (ADROP) s[kt] *= keep[kt];                              // the P image feeds dV only: A = D o P
+        }
+        BLK_STAMP(4);
+        float* gtile = dqkv + tok0 * rs + head * HD + 4 * lr;
+        // dQ[q][c] = scale * sum_key dS[q][key] K[key][c]
+        {
+            f32x4v acc[4];
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4v{0.f, 0.f, 0.f, 0.f};
+            regs_times_col(Kt, dp, lr, gq, acc);
+            store_rows(gtile, rs, acc, SCALE, gq, n_real);
+        }
+        BLK_STAMP(5);
+        wait_lds_barrier();                                      // every wave is through with the K and V images
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {                         // [query][key] images: keys 16 kt + 4g .. + 3 = chunk 4 kt + g
+            *(lds_f32x4*)(Pt + chunk_off_f(slot, 4 * kt + gq)) = s[kt];
+            *(lds_f32x4*)(Dt + chunk_off_f(slot, 4 * kt + gq)) = dp[kt];
+        }
+        wait_lds_barrier();                                      // P, dS of all four query groups are in the images
+        BLK_STAMP(6);
+
+        // ================================================= phase B: key slot `slot`
+        {
+            f32x4v dk[4], dv[4];
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) { dk[ct] = f32x4v{0.f, 0.f, 0.f, 0.f}; dv[ct] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
+            const int kc = 4 * w + (lr >> 2), kb = (lr & 3) * 4; // this lane's key column of the [query][key] images
+#pragma unroll
+            for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int qrow = 16 * qt + 4 * gq + r;
+                    const f32x4v qa = col_op_f(Qt, qrow, lr), ga = col_op_f(Gt, qrow, lr);
+                    const float dsb = *(const lds_f32*)(Dt + chunk_off_f(qrow, kc) + kb);
+                    const float pb = *(const lds_f32*)(Pt + chunk_off_f(qrow, kc) + kb);
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct) {
+                        dk[ct] = mfma4(dsb, qa[ct], dk[ct]);                     // dK[key][c] += sum_q dS[q][key] Q[q][c]
+                        dv[ct] = mfma4(pb, ga[ct], dv[ct]);                      // dV[key][c] += sum_q P[q][key] dO[q][c]
+                    }
+                }
+            BLK_STAMP(7);
+            // the next unit's rows go to the images BEFORE this unit's last stores are issued: waiting for those loads (vmcnt
+            // counts in order) then does not wait for the stores, which a wait at the top of the loop would (stamps: 18 % of a unit)
+            if (more) {
+                wait_lds_barrier();                              // every wave is through with the images
+                BLK_STAMP(8);
+                put_unit<4>(sm, nx, lane, w);
+            }
+            store_rows(gtile + g.d, rs, dk, SCALE, gq, n_real);
+            store_rows(gtile + 2 * g.d, rs, dv, 1.0f, gq, n_real);
+        }
+        if (!more) break;
+        BLK_STAMP(0);
+        advance();
+        BLK_STAMP(1);
+        wait_lds_barrier();
+        BLK_STAMP_NEXT();
     }
 }
 
@@ -275,10 +417,11 @@ int hwgat_launch_blk_fwd_f32(const void* qkv, void* o, const uint32_t* maskbits,
     const AttnDrop ad = make_drop(drop_seed, drop_p, seed_base);
     BlkGeom g{F, KJ, nH, F / 2, nH * HD, shifted ? 1 : 0};
     const int64_t units = (int64_t)B * g.f * nH;
-    const int64_t clip_bytes = (int64_t)F * KJ * 3 * g.d * 4;
-    if (units > 0x7fffffff || clip_bytes > 0x7fffffff) return HWGAT_ESHAPE;
-    if (ad.p > 0.f) blk_fwd_f32_k<true><<<(int)units, 256, 0, st>>>((const float*)qkv, (float*)o, maskbits, g, clip_bytes * B, ad);
-    else blk_fwd_f32_k<false><<<(int)units, 256, 0, st>>>((const float*)qkv, (float*)o, maskbits, g, clip_bytes * B, ad);
+    if (units > 0x7fffffff) return HWGAT_ESHAPE;
+    const int blocks = (int)min(units, (int64_t)256 * 3);        // 48 KB of LDS: three workgroups per CU
+    const int skew = lab_env("HWGAT_BLK_SKEW") ? atoi(lab_env("HWGAT_BLK_SKEW")) : 0;
+    if (ad.p > 0.f) blk_fwd_f32_k<true><<<blocks, 256, 0, st>>>((const float*)qkv, (float*)o, maskbits, g, (int)units, ad, skew);
+    else blk_fwd_f32_k<false><<<blocks, 256, 0, st>>>((const float*)qkv, (float*)o, maskbits, g, (int)units, ad, skew);
     HWGAT_LAUNCH_CHECK();
 }
 
@@ -287,13 +430,18 @@ int hwgat_launch_blk_bwd_f32(const void* qkv, const void* dO, void* dqkv, const 
     const AttnDrop ad = make_drop(drop_seed, drop_p, seed_base);
     BlkGeom g{F, KJ, nH, F / 2, nH * HD, shifted ? 1 : 0};
     const int64_t units = (int64_t)B * g.f * nH;
-    const int64_t clip_bytes = (int64_t)F * KJ * 3 * g.d * 4;
-    if (units > 0x7fffffff || clip_bytes > 0x7fffffff) return HWGAT_ESHAPE;
+    if (units > 0x7fffffff) return HWGAT_ESHAPE;
+    const int blocks = (int)min(units, (int64_t)256 * 2);        // 64 KB of LDS: two workgroups per CU
+    const int skew = lab_env("HWGAT_BLK_SKEW") ? atoi(lab_env("HWGAT_BLK_SKEW")) : 0;
     if (ad.p > 0.f)
-        blk_bwd_f32_k<true><<<(int)units, 256, 0, st>>>((const float*)qkv, (const float*)dO, (float*)dqkv, maskbits, g,
-                                                        clip_bytes * B, clip_bytes * B / 3, ad);
+        blk_bwd_f32_k<true><<<blocks, 256, 0, st>>>((const float*)qkv, (const float*)dO, (float*)dqkv, maskbits, g, (int)units, ad, skew);
     else
-        blk_bwd_f32_k<false><<<(int)units, 256, 0, st>>>((const float*)qkv, (const float*)dO, (float*)dqkv, maskbits, g,
-                                                         clip_bytes * B, clip_bytes * B / 3, ad);
+        blk_bwd_f32_k<false><<<blocks, 256, 0, st>>>((const float*)qkv, (const float*)dO, (float*)dqkv, maskbits, g, (int)units, ad, skew);
     HWGAT_LAUNCH_CHECK();
 }
+
+#ifdef HWGAT_LAB
+extern "C" int hwgat_lab_blk_stamps(void* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_blk_stamps), &buf, sizeof(buf)) == hipSuccess ? 0 : HWGAT_EINVAL;
+}
+#endif

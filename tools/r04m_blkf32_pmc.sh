@@ -1,3 +1,4 @@
-# round 4: wave-cycle / wait / LDS-conflict / MFMA-busy counters of the four-wave fp32 block attention kernels
 python sl-hwgat_amd/build.py > /dev/null 2>&1; echo "build rc $?"
-PMC_OUT=r04m PMC_ARGS=f32 PMC_FILTER=blk_ bash tools/blk_pmc.sh
+python sl-hwgat_amd/build.py --lab > /dev/null 2>&1; echo "lab build rc $?"
+mkdir -p gpurun_out/r04m
+timeout -k 10 120 python tools/blk_stamps.py > gpurun_out/r04m/blk_stamps.txt 2>&1; echo "rc $?"; cat gpurun_out/r04m/blk_stamps.txt
