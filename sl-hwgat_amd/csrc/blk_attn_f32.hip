@@ -100,7 +100,7 @@ __device__ __forceinline__ LaneOffs lane_offs(const BlkGeom& g, int lane, int w)
 //  behind a wait for every outstanding store)
 __device__ __forceinline__ u32x4v ld16(const float* base, uint32_t byte_off) {
     asm volatile("" : "+v"(byte_off));
-    return *reinterpret_cast<const u32x4v*>(reinterpret_cast<const char*>(base) + byte_off);
+    return __builtin_nontemporal_load(reinterpret_cast<const u32x4v*>(reinterpret_cast<const char*>(base) + byte_off));
 }
 // load jj of the four (the NIMG images' slot rows 16w + 4jj .. + 3)
 template <int NIMG>
@@ -138,19 +138,90 @@ __device__ __forceinline__ void start_skew(int skew, int per_cu) {
     for (int i = 0; i < k * (skew & 0xffff); ++i) __builtin_amdgcn_s_sleep(1);
 }
 
-// X (+)= sum over the 64 key (query) slots of  b[slot] img[slot][channel]:  acc[ct][r] = channel 4 l + ct of row 4 g + r of the
-// wave's 16 queries (keys), where b[kt][r] is the lane's value for slot 16 kt + 4 g + r (the result layout of phase A, here the A
-// operand: row i of the product = query l) and one ds_read_b128 of chunk l of a slot row feeds the four channel tiles (the B
-// operand: column j of tile ct = channel 4 j + ct).  The sixteen lanes l of a register then hold one whole 256-byte row.
-__device__ __forceinline__ void regs_times_col(const char* img, const f32x4v (&b)[4], int lr, int gq, f32x4v (&acc)[4]) {
+// ---- products tile by tile (16 key / query slots), skipping the tiles that contribute exactly nothing.  The adjacency of a
+// skeleton is sparse (0.075 for the reference's; 4 of its 16 tiles of 16 x 16 slots are empty): a tile of S whose keys no
+// query of the wave sees is never looked at (the masks replace it by -10000), and a tile of P (dS) that is zero in every
+// lane adds zeros to O, delta, dQ, dK, dV.  The tests are wave-uniform ballots on the registers themselves, so the result is
+// the dense one bit for bit whatever the masks and the data (a row without any visible key has P != 0 everywhere and skips
+// nothing); the branch keeps EXEC whole for the MFMAs.
+// bit kt: some lane's (query's) mask words show a key of tile kt (keys 16 (kt & 1) .. + 15 of frame kt >> 1)
+__device__ __forceinline__ uint32_t vis_tiles(uint32_t mb0, uint32_t mb1) {
+    uint32_t v = 0;
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt)
+        v |= __builtin_amdgcn_ballot_w64((((kt >> 1 ? mb1 : mb0) >> (16 * (kt & 1))) & 0xffffu) != 0) != 0 ? 1u << kt : 0u;
+    return v;
+}
+__device__ __forceinline__ bool tile_any(const f32x4v& x) {
+    return __builtin_amdgcn_ballot_w64(x.x != 0.f || x.y != 0.f || x.z != 0.f || x.w != 0.f) != 0;
+}
+// the four row operands (channel chunks 4 m + g, m = 0..3) of slot row `row`
+__device__ __forceinline__ void row_ops4(f32x4v (&x)[4], const char* img, int row, int gq) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const f32x4v v = col_op_f(img, 16 * kt + 4 * gq + r, lr);
+    for (int m = 0; m < 4; ++m) x[m] = row_op_f(img, row, m, gq);
+}
+// one 16 x 16 tile of X Y^T over the 64 channels: lane (l, g), register r = X row 4 g + r against Y row l.  Two accumulation
+// chains: back-to-back MFMAs into one accumulator wait 40 cycles for each other where independent ones issue every 32.
+__device__ __forceinline__ f32x4v xyT16(const f32x4v (&x)[4], const f32x4v (&y)[4]) {
+    f32x4v a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ct = 0; ct < 4; ++ct) acc[ct] = mfma4(b[kt][r], v[ct], acc[ct]);
+    for (int m = 0; m < 4; ++m) {
+        a = mfma4(x[m][0], y[m][0], a);
+        b = mfma4(x[m][1], y[m][1], b);
+        a = mfma4(x[m][2], y[m][2], a);
+        b = mfma4(x[m][3], y[m][3], b);
+    }
+    return a + b;
+}
+// S^T-shaped product of the wave's 16 rows of `y` (row operands in registers) with the 64 slot rows of `img`, tile kt only
+// where need(kt); the operands of tile kt + 1 are read while tile kt multiplies (read or not: a skipped tile costs 4 reads)
+template <typename Need>
+__device__ __forceinline__ void rows_xyT(f32x4v (&out)[4], const char* img, const f32x4v (&y)[4], int lr, int gq, Need need) {
+    f32x4v x[2][4];
+    row_ops4(x[0], img, lr, gq);
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+        if (kt < 3) row_ops4(x[(kt + 1) & 1], img, 16 * (kt + 1) + lr, gq);
+        if (need(kt)) out[kt] = xyT16(x[kt & 1], y);
+        else out[kt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    }
+}
+// the four column operands (chunk l) of the slot rows 16 t + 4 g + r, r = 0..3, of `img`
+__device__ __forceinline__ void col_ops4(f32x4v (&v)[4], const char* img, int t, int lr, int gq) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = col_op_f(img, 16 * t + 4 * gq + r, lr);
+}
+// acc[ct][r] += sum over the 16 slots of tile t of  b[r'] v[r'][ct]:  channel 4 l + ct of row 4 g + r of the wave's 16 queries
+// (keys); b[r'] is the lane's value for slot 16 t + 4 g + r' (the A operand: row i of the product = the lane's l) and v[r'] one
+// ds_read_b128 of chunk l of that slot row (the B operand: column j of channel tile ct = channel 4 j + ct).  The sixteen lanes
+// l of a result register then hold one whole 256-byte row.
+__device__ __forceinline__ void tile_times_col(const f32x4v& b, const f32x4v (&v)[4], f32x4v (&acc)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) acc[ct] = mfma4(b[r], v[r][ct], acc[ct]);
+}
+// acc += b img over the 64 key slots (b = P or dS in the result layout of phase A); SKIP: tile by tile, where b has a non-zero
+template <bool SKIP>
+__device__ __forceinline__ void regs_times_col(const char* img, const f32x4v (&b)[4], int lr, int gq, f32x4v (&acc)[4]) {
+    if constexpr (SKIP) {
+        f32x4v v[2][4];
+        col_ops4(v[0], img, 0, lr, gq);
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            if (kt < 3) col_ops4(v[(kt + 1) & 1], img, kt + 1, lr, gq);
+            if (tile_any(b[kt])) tile_times_col(b[kt], v[kt & 1], acc);
         }
+    } else {
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const f32x4v v = col_op_f(img, 16 * kt + 4 * gq + r, lr);
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) acc[ct] = mfma4(b[kt][r], v[ct], acc[ct]);
+            }
+    }
 }
 // rows 4 g + r < n_real of the wave's 16-row tile (scaled): 16 bytes per lane, 4 whole rows per store instruction (lanes that
 // each own 16 channels of one row -- 64 scattered 16-byte pieces per instruction -- cost the backward pass 19 %: LABLOG 10.8)
@@ -158,7 +229,8 @@ __device__ __forceinline__ void store_rows(float* tile, int64_t row_stride, cons
 #pragma unroll
     for (int r = 0; r < 4; ++r)
         if (4 * gq + r < n_real)
-            *reinterpret_cast<f32x4v*>(tile + (4 * gq + r) * row_stride) = f32x4v{acc[0][r], acc[1][r], acc[2][r], acc[3][r]} * scale;
+            __builtin_nontemporal_store(f32x4v{acc[0][r], acc[1][r], acc[2][r], acc[3][r]} * scale,
+                                        reinterpret_cast<f32x4v*>(tile + (4 * gq + r) * row_stride));
 }
 
 // =============================================================== forward
@@ -202,13 +274,15 @@ __global__ __launch_bounds__(256, 3) void blk_fwd_f32_k(const float* __restrict_
     advance();
     wait_lds_barrier();
     for (;;) {
+        // S[q][key 16 kt + 4g + r]: the four key tiles side by side (the forward pass has the registers of three waves per SIMD
+        // to live in, and tile-by-tile products with their skip tests were slower here: LABLOG 10.8).  A quarter of the next
+        // unit's rows is fetched per step: sixteen loads in one burst from every wave of the CU fill the address queue, and a
+        // wave that cannot issue its load issues no MFMA either
         f32x4v s[4];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) s[kt] = f32x4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            // a quarter of the next unit's rows per step: sixteen loads in one burst from every wave of the CU fill the
-            // address queue, and a wave that cannot issue its load issues no MFMA either
             if (more) fetch_part<3>(nx, m, qkv, nullptr, g, un, lo, w);
             const f32x4v q = row_op_f(Qt, slot, m, gq);
             f32x4v k[4];
@@ -217,7 +291,7 @@ __global__ __launch_bounds__(256, 3) void blk_fwd_f32_k(const float* __restrict_
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int kt = 0; kt < 4; ++kt) s[kt] = mfma4(k[kt][e], q[e], s[kt]);      // S[q][key 16 kt + 4g + r]
+                for (int kt = 0; kt < 4; ++kt) s[kt] = mfma4(k[kt][e], q[e], s[kt]);
             __builtin_amdgcn_sched_barrier(0);
         }
         uint32_t nz;
@@ -233,7 +307,7 @@ __global__ __launch_bounds__(256, 3) void blk_fwd_f32_k(const float* __restrict_
         f32x4v acc[4];
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4v{0.f, 0.f, 0.f, 0.f};
-        regs_times_col(Vt, s, lr, gq, acc);                     // (products outside any lane-dependent branch: MFMAs want all lanes)
+        regs_times_col<false>(Vt, s, lr, gq, acc);              // (products outside any lane-dependent branch: MFMAs want all lanes)
         // the next unit's rows go to the images BEFORE this unit's stores are issued: waiting for those loads (vmcnt counts in
         // order) then does not wait for the stores, which a wait at the top of the loop would (stamps: 18 % of a unit)
         float* otile = o + tok0 * (int64_t)g.d + head * HD + 4 * lr;
@@ -281,10 +355,11 @@ __global__ __launch_bounds__(256, 2) void blk_bwd_f32_k(const float* __restrict_
     start_skew(skew, 2);
     // the query's mask words, both variants (plain / last block of a shifted layer): no loads besides the prefetch in the loop
     const uint32_t mp0 = maskbits[slot * 2], mp1 = maskbits[slot * 2 + 1], ml0 = maskbits[(64 + slot) * 2], ml1 = maskbits[(64 + slot) * 2 + 1];
+    const uint32_t vis_p = vis_tiles(mp0, mp1), vis_l = vis_tiles(ml0, ml1);
     // the unit in the images (tok0, head, ucur, mb0, mb1: the mask words of the query) and the one in flight (un, nx)
     int64_t tok0;                                                // first token of the wave's 16-slot tile
     int head, ucur;
-    uint32_t mb0, mb1;
+    uint32_t mb0, mb1, vis;                                      // vis: bit kt = some query of the wave sees a key of tile kt
     bool more;
     auto advance = [&]() {
         tok0 = (w >> 1 ? un.base[1] : un.base[0]) + 16 * (w & 1);
@@ -292,6 +367,7 @@ __global__ __launch_bounds__(256, 2) void blk_bwd_f32_k(const float* __restrict_
         ucur = u;
         mb0 = un.mrow ? ml0 : mp0;
         mb1 = un.mrow ? ml1 : mp1;
+        vis = un.mrow ? vis_l : vis_p;
         u += gridDim.x;
         more = u < n_units;
         if (more) un = decode_bunit(g, u);
@@ -304,41 +380,39 @@ __global__ __launch_bounds__(256, 2) void blk_bwd_f32_k(const float* __restrict_
         BLK_STAMP(2);
 
         // ================================================= phase A: query slot `slot`
+        // S[q][key 16 kt + 4g + r], only the key tiles some query of the wave sees.  A quarter of the next unit's rows is
+        // fetched per tile: sixteen loads in one burst from every wave of the CU fill the address queue, and a wave that cannot
+        // issue its load issues no MFMA either
         f32x4v s[4], dp[4];
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) { s[kt] = f32x4v{0.f, 0.f, 0.f, 0.f}; dp[kt] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            // a quarter of the next unit's rows per step: sixteen loads in one burst from every wave of the CU fill the
-            // address queue, and a wave that cannot issue its load issues no MFMA either
+        {
+            f32x4v q[4];
+            row_ops4(q, Qt, slot, gq);
+            rows_xyT(s, Kt, q, lr, gq, [&](int kt) {
 #ifdef HWGAT_LAB
-            if (!no_fetch)
+                if (!no_fetch)
 #endif
-            if (more) fetch_part<4>(nx, m, qkv, dO, g, un, lo, w);
-            const f32x4v q = row_op_f(Qt, slot, m, gq), gd = row_op_f(Gt, slot, m, gq);
-            f32x4v k[4], v[4];
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) { k[kt] = row_op_f(Kt, 16 * kt + lr, m, gq); v[kt] = row_op_f(Vt, 16 * kt + lr, m, gq); }
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int kt = 0; kt < 4; ++kt) {
-                    s[kt] = mfma4(k[kt][e], q[e], s[kt]);                        // S[q][key 16 kt + 4g + r]
-                    dp[kt] = mfma4(v[kt][e], gd[e], dp[kt]);                     // dP[q][key]
-                }
-            __builtin_amdgcn_sched_barrier(0);
+                if (more) fetch_part<4>(nx, kt, qkv, dO, g, un, lo, w);
+                return (vis >> kt) & 1;
+            });
         }
         BLK_STAMP(3);
         uint32_t nz;
         const float sum = masked_exp64(s, mb0, mb1, gq, g.KJ, nz);
         const float inv = real ? 1.0f / sum : 0.f;                               // pad query slots: P = dS = 0
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) s[kt] *= inv;                             // P (HGATE.py:105)
+        // dP[q][key] = dO V^T, only the tiles where P is not zero throughout (delta and dS take nothing from the others)
+        {
+            f32x4v gd[4];
+            row_ops4(gd, Gt, slot, gq);
+            rows_xyT(dp, Vt, gd, lr, gq, [&](int kt) { return tile_any(s[kt]); });
+        }
         // attention dropout: A = D o P went into O = A V, so dP = D o dA (dA = dO V^T, in `dp`) and dV = A^T dO; mask recomputed
         f32x4v keep[ADROP ? 4 : 1];
         if constexpr (ADROP) blk_keep16(keep, ad, ucur, slot, gq, g.KJ);
         float delta = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
-            s[kt] *= inv;                                                        // P (HGATE.py:105)
             if constexpr (ADROP) dp[kt] *= keep[kt];
 #pragma unroll
             for (int r = 0; r < 4; ++r) delta = __builtin_fmaf(s[kt][r], dp[kt][r], delta);
@@ -357,7 +431,7 @@ __global__ __launch_bounds__(256, 2) void blk_bwd_f32_k(const float* __restrict_
             f32x4v acc[4];
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4v{0.f, 0.f, 0.f, 0.f};
-            regs_times_col(Kt, dp, lr, gq, acc);
+            regs_times_col<true>(Kt, dp, lr, gq, acc);
             store_rows(gtile, rs, acc, SCALE, gq, n_real);
         }
         BLK_STAMP(5);
@@ -375,21 +449,29 @@ __global__ __launch_bounds__(256, 2) void blk_bwd_f32_k(const float* __restrict_
             f32x4v dk[4], dv[4];
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) { dk[ct] = f32x4v{0.f, 0.f, 0.f, 0.f}; dv[ct] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
-            const int kc = 4 * w + (lr >> 2), kb = (lr & 3) * 4; // this lane's key column of the [query][key] images
+            // the lane's key column of the [query][key] images: d[qt][r] = dS[query 16 qt + 4g + r][key], p likewise; a query
+            // tile whose dS (P) is zero for every key of the wave adds nothing to dK (dV)
+            const uint32_t kcol = (uint32_t)(lr & 3) * 4;
+            f32x4v d[4], pq[4];
 #pragma unroll
             for (int qt = 0; qt < 4; ++qt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int qrow = 16 * qt + 4 * gq + r;
-                    const f32x4v qa = col_op_f(Qt, qrow, lr), ga = col_op_f(Gt, qrow, lr);
-                    const float dsb = *(const lds_f32*)(Dt + chunk_off_f(qrow, kc) + kb);
-                    const float pb = *(const lds_f32*)(Pt + chunk_off_f(qrow, kc) + kb);
-#pragma unroll
-                    for (int ct = 0; ct < 4; ++ct) {
-                        dk[ct] = mfma4(dsb, qa[ct], dk[ct]);                     // dK[key][c] += sum_q dS[q][key] Q[q][c]
-                        dv[ct] = mfma4(pb, ga[ct], dv[ct]);                      // dV[key][c] += sum_q P[q][key] dO[q][c]
-                    }
+                    const uint32_t off = chunk_off_f(16 * qt + 4 * gq + r, 4 * w + (lr >> 2)) + kcol;
+                    d[qt][r] = *(const lds_f32*)(Dt + off);
+                    pq[qt][r] = *(const lds_f32*)(Pt + off);
                 }
+            // dK[key][c] += sum_q dS[q][key] Q[q][c] and dV[key][c] += sum_q P[q][key] dO[q][c] as eight blocks (qt, dK | dV),
+            // the column operands of a block read while the block before multiplies
+            f32x4v v[2][4];
+            col_ops4(v[0], Qt, 0, lr, gq);
+#pragma unroll
+            for (int qt = 0; qt < 4; ++qt) {
+                col_ops4(v[1], Gt, qt, lr, gq);
+                if (tile_any(d[qt])) tile_times_col(d[qt], v[0], dk);
+                if (qt < 3) col_ops4(v[0], Qt, qt + 1, lr, gq);
+                if (tile_any(pq[qt])) tile_times_col(pq[qt], v[1], dv);
+            }
             BLK_STAMP(7);
             // the next unit's rows go to the images BEFORE this unit's last stores are issued: waiting for those loads (vmcnt
             // counts in order) then does not wait for the stores, which a wait at the top of the loop would (stamps: 18 % of a unit)

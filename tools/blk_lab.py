@@ -38,7 +38,9 @@ def timed(fn, n=20):
 
 fwd = lambda: HF.attn_fwd("blk", qkv, o, bits, None, nH, False)
 bwd = lambda: HF.attn_bwd("blk", qkv, do, dq, bits, None, nH, False)
-for skew in [int(a) for a in (sys.argv[1:] or "0 32 64 96 128 192 256 320 384 512".split())]:
-    os.environ["HWGAT_BLK_SKEW"] = str(skew)
-    tf, tb = timed(fwd), timed(bwd)
-    print(f"skew {skew:4d}: fwd {tf:7.1f} us {4 * E / tf / 1e6:5.2f} TB/s | bwd {tb:7.1f} us {7 * E / tb / 1e6:5.2f} TB/s", flush=True)
+for occ in (2, 3):
+    os.environ["HWGAT_BLK_OCC"] = str(occ)
+    for skew in [int(a) for a in (sys.argv[1:] or "0 128 256".split())]:
+        os.environ["HWGAT_BLK_SKEW"] = str(skew)
+        tf, tb = timed(fwd), timed(bwd)
+        print(f"fwd workgroups per CU {occ} skew/flags {skew:#8x}: fwd {tf:7.1f} us {4 * E / tf / 1e6:5.2f} TB/s | bwd {tb:7.1f} us {7 * E / tb / 1e6:5.2f} TB/s", flush=True)
