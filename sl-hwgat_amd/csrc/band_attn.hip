@@ -47,8 +47,17 @@ template <typename T> __device__ __forceinline__ f32x4v ld4(const T* p) {
         return r;
     }
 }
-template <typename T> __device__ __forceinline__ float ld1(const T* p) { return (float)*p; }
-template <typename T> __device__ __forceinline__ void st1(T* p, float v) { *p = (T)v; }
+// N = 1 or 2 consecutive elements <-> floats, one memory instruction
+template <typename T, int N> __device__ __forceinline__ void ldn(const T* p, float (&v)[N]) {
+    if constexpr (N == 1) v[0] = (float)*p;
+    else if constexpr (sizeof(T) == 4) { const f32x2 t = *reinterpret_cast<const f32x2*>(p); v[0] = t.x; v[1] = t.y; }
+    else { const bf16x2 t = *reinterpret_cast<const bf16x2*>(p); v[0] = (float)t.x; v[1] = (float)t.y; }
+}
+template <typename T, int N> __device__ __forceinline__ void stn(T* p, const float (&v)[N]) {
+    if constexpr (N == 1) *p = (T)v[0];
+    else if constexpr (sizeof(T) == 4) *reinterpret_cast<f32x2*>(p) = f32x2{v[0], v[1]};
+    else *reinterpret_cast<bf16x2*>(p) = bf16x2{(bf16_t)v[0], (bf16_t)v[1]};
+}
 
 __device__ __forceinline__ float xg_max(float v) {              // over the 4 lanes l, l^16, l^32, l^48
     v = fmaxf(v, __shfl_xor(v, 16, 64));
@@ -61,7 +70,10 @@ __device__ __forceinline__ float xg_sum(float v) {
 
 // row-operand tile: X[row = l&15][c = 16*ch + 4*g + s]  (A or B^T operand of a head-dim contraction)
 template <int NC> struct RowT { f32x4v c[NC]; };
-// column-operand tile: X[row = 4*g + r][c = 16*ct + (l&15)]  (B operand of a row contraction)
+// column-operand tile: X[row = 4*g + r][c = NC*(l&15) + ct]  (B operand of a row contraction: column j of channel tile ct is
+// channel NC j + ct, so a lane's NC tiles are NC consecutive elements = one load per row, and the product comes out as NC
+// consecutive channels per lane = one store per row; with tile ct = channels 16 ct + j every head_dim-32 column load and
+// store was two 4-byte instructions)
 template <int NC> struct ColT { float v[NC][4]; };
 
 // `base` is wave-uniform (SGPR pair), `off` a 32-bit per-lane element offset: the loads use the
@@ -75,14 +87,26 @@ __device__ __forceinline__ RowT<NC> load_row(const T* base, uint32_t off, float 
 }
 template <typename T, int NC>
 __device__ __forceinline__ ColT<NC> load_col(const T* base, int64_t row_stride, uint32_t off, float mul) {
-    ColT<NC> t;                                                  // off = 4 * g * row_stride + (l&15)
+    ColT<NC> t;                                                  // off = 4 * g * row_stride + NC * (l&15)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const T* b = base + r * row_stride;
+        float x[NC];
+        ldn<T, NC>(base + r * row_stride + off, x);
 #pragma unroll
-        for (int ct = 0; ct < NC; ++ct) t.v[ct][r] = ld1<T>(b + off + 16 * ct) * mul;
+        for (int ct = 0; ct < NC; ++ct) t.v[ct][r] = x[ct] * mul;
     }
     return t;
+}
+// rows 4g + r of a product in the column layout (acc[ct][r] = channel NC (l&15) + ct of row 4g + r), scaled
+template <typename T, int NC>
+__device__ __forceinline__ void store_col(T* base, int64_t row_stride, uint32_t off, const f32x4v (&acc)[NC], float mul) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float x[NC];
+#pragma unroll
+        for (int ct = 0; ct < NC; ++ct) x[ct] = acc[ct][r] * mul;
+        stn<T, NC>(base + r * row_stride + off, x);
+    }
 }
 template <int NC> __device__ __forceinline__ RowT<NC> zero_row() {
     RowT<NC> t;
@@ -180,8 +204,8 @@ __global__ __launch_bounds__(256, MINW) void band_attn_fwd_k(const T* __restrict
     T* ob = o + un.tok0 * (int64_t)g.d + un.head * HD;
     const int64_t fs = (int64_t)g.K * rs;                        // frame stride in qkv
     const uint64_t mrow = maskrows[un.w * 16 + lr];
-    const uint32_t roff = lr * (uint32_t)rs + 4 * gq, coff = 4 * gq * (uint32_t)rs + lr;   // per-lane offsets in qkv
-    const uint32_t ooff = 4 * gq * (uint32_t)g.d + lr;                                     // ... and in o
+    const uint32_t roff = lr * (uint32_t)rs + 4 * gq, coff = 4 * gq * (uint32_t)rs + NC * lr;   // per-lane offsets in qkv
+    const uint32_t ooff = 4 * gq * (uint32_t)g.d + NC * lr;                                     // ... and in o
 
     // sliding window: K (row operand) and V (column operand) of frames f-1, f, f+1
     RowT<NC> kw[3];
@@ -236,12 +260,8 @@ __global__ __launch_bounds__(256, MINW) void band_attn_fwd_k(const T* __restrict
                 for (int ct = 0; ct < NC; ++ct) oacc[ct] = f32x4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int t = 0; t < 3; ++t) mul_cols<NC>(p[t], vw[t], oacc);
-                // lane (c = lr, g), reg r -> O[q = 4g + r][16 ct + c]
-                T* of = ob + (int64_t)f * g.K * g.d;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int ct = 0; ct < NC; ++ct) st1<T>(of + r * (int64_t)g.d + ooff + 16 * ct, oacc[ct][r]);
+                // lane (c = lr, g), reg r -> O[q = 4g + r][NC c + ct]
+                store_col<T, NC>(ob + (int64_t)f * g.K * g.d, g.d, ooff, oacc, 1.0f);
             }
             kw[0] = kw[1]; kw[1] = kw[2];
             vw[0] = vw[1]; vw[1] = vw[2];
@@ -277,8 +297,8 @@ __global__ __launch_bounds__(256, MINW) void band_attn_bwd_k(const T* __restrict
     const T* gb = dO + un.tok0 * (int64_t)g.d + un.head * HD;
     T* db = dqkv + un.tok0 * rs + un.head * HD;
     const uint64_t mrow = maskrows[un.w * 16 + lr];              // row of query joint lr
-    const uint32_t roff = lr * (uint32_t)rs + 4 * gq, coff = 4 * gq * (uint32_t)rs + lr;       // lane offsets in qkv / dqkv
-    const uint32_t groff = lr * (uint32_t)g.d + 4 * gq, gcoff = 4 * gq * (uint32_t)g.d + lr;  // ... in dO
+    const uint32_t roff = lr * (uint32_t)rs + 4 * gq, coff = 4 * gq * (uint32_t)rs + NC * lr;       // lane offsets in qkv / dqkv
+    const uint32_t groff = lr * (uint32_t)g.d + 4 * gq, gcoff = 4 * gq * (uint32_t)g.d + NC * lr;  // ... in dO
     uint64_t mrow2[4];                                           // rows of query joints 4g + r (transposed tiles)
 #pragma unroll
     for (int r = 0; r < 4; ++r) mrow2[r] = maskrows[un.w * 16 + 4 * gq + r];
@@ -322,14 +342,8 @@ __global__ __launch_bounds__(256, MINW) void band_attn_bwd_k(const T* __restrict
     for (int i = 0; i < PF; ++i) fill(i, i);
 
     auto store_key = [&](int f, const f32x4v (&k)[NC], const f32x4v (&v)[NC]) {
-        T* row = db + f * fs;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int ct = 0; ct < NC; ++ct) {
-                st1<T>(row + r * rs + g.d + coff + 16 * ct, k[ct][r]);
-                st1<T>(row + r * rs + 2 * g.d + coff + 16 * ct, v[ct][r]);
-            }
+        store_col<T, NC>(db + f * fs + g.d, rs, coff, k, 1.0f);
+        store_col<T, NC>(db + f * fs + 2 * g.d, rs, coff, v, 1.0f);
     };
 
     for (int fb = 0; fb < g.F; fb += PF) {
@@ -368,14 +382,7 @@ __global__ __launch_bounds__(256, MINW) void band_attn_bwd_k(const T* __restrict
                 for (int ct = 0; ct < NC; ++ct) acc[ct] = f32x4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int t = 0; t < 3; ++t) mul_cols<NC>(ds[t], kw[t].kc, acc);
-                {
-                    T* row = db + f * fs;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-#pragma unroll
-                        for (int ct = 0; ct < NC; ++ct)
-                            st1<T>(row + r * rs + coff + 16 * ct, acc[ct][r] * band_scale<HD>());
-                }
+                store_col<T, NC>(db + f * fs, rs, coff, acc, band_scale<HD>());
                 // ---- orientation 2: lane = key joint lr, registers = query joints 4g + r
                 if constexpr (XPOSE) {
 #pragma unroll
@@ -482,7 +489,13 @@ extern "C" int hwgat_band_attn_fwd_drop(const void* qkv, void* o, const uint64_t
         else band_attn_fwd_k<T, 16, 4, 3, true><<<blocks, 256, 0, st>>>(FWD_ARGS(T));                \
     } else if (hd == 32) band_attn_fwd_k<T, 32, 4, 1><<<blocks, 256, 0, st>>>(FWD_ARGS(T));          \
     else band_attn_fwd_k<T, 16, 4, 3><<<blocks, 256, 0, st>>>(FWD_ARGS(T));
-    if (dtype == HWGAT_F32) { FWD(float) }
+    if (dtype == HWGAT_F32) {
+        // head_dim 16 (WGATE): the workgroup-staged kernels of band_attn_f32.hip; the one-wave-per-head form stays for
+        // head_dim 32 and as the lab A/B (HWGAT_BAND_F32=0)
+        static const bool old_f32 = lab_env("HWGAT_BAND_F32") && lab_env("HWGAT_BAND_F32")[0] == '0';
+        if (hd == 16 && !old_f32) return hwgat_launch_band_fwd_f32(qkv, o, maskrows, B, F, nW, nH, ad.seed, ad.p, ad.base, st);
+        FWD(float)
+    }
     else if (dtype == HWGAT_BF16) {
         if (!old_b16) return hwgat_launch_band_fwd_b16(qkv, o, maskrows, B, F, nW, nH, hd, ad.seed, ad.p, ad.base, st);
         FWD(bf16_t)
@@ -522,7 +535,11 @@ extern "C" int hwgat_band_attn_bwd_drop(const void* qkv, const void* dO, void* d
     else if (hd == 32) band_attn_bwd_k<T, 32, 1, 1, false><<<blocks, 256, 0, st>>>(BWD_ARGS(T));     \
     else if (xpose) band_attn_bwd_k<T, 16, 2, 2, true><<<blocks, 256, 0, st>>>(BWD_ARGS(T));         \
     else band_attn_bwd_k<T, 16, 2, 2, false><<<blocks, 256, 0, st>>>(BWD_ARGS(T));
-    if (dtype == HWGAT_F32) { BWD(float) }
+    if (dtype == HWGAT_F32) {
+        static const bool old_f32 = lab_env("HWGAT_BAND_F32") && lab_env("HWGAT_BAND_F32")[0] == '0';
+        if (hd == 16 && !old_f32) return hwgat_launch_band_bwd_f32(qkv, dO, dqkv, maskrows, B, F, nW, nH, ad.seed, ad.p, ad.base, st);
+        BWD(float)
+    }
     else if (dtype == HWGAT_BF16) {
         if (!old_b16) return hwgat_launch_band_bwd_b16(qkv, dO, dqkv, maskrows, B, F, nW, nH, hd, ad.seed, ad.p, ad.base, st);
         BWD(bf16_t)

@@ -62,3 +62,8 @@ int hwgat_launch_band_fwd_b16(const void* qkv, void* o, const uint64_t* maskrows
                               uint32_t drop_seed, float drop_p, const uint32_t* seed_base, hipStream_t st);
 int hwgat_launch_band_bwd_b16(const void* qkv, const void* dO, void* dqkv, const uint64_t* maskrows, int B, int F, int nW,
                               int nH, int hd, uint32_t drop_seed, float drop_p, const uint32_t* seed_base, hipStream_t st);
+// fp32 storage and arithmetic, head_dim 16: 16x16x4 fp32 MFMA tiles, workgroup-staged whole-row tiles (band_attn_f32.hip)
+int hwgat_launch_band_fwd_f32(const void* qkv, void* o, const uint64_t* maskrows, int B, int F, int nW, int nH,
+                              uint32_t drop_seed, float drop_p, const uint32_t* seed_base, hipStream_t st);
+int hwgat_launch_band_bwd_f32(const void* qkv, const void* dO, void* dqkv, const uint64_t* maskrows, int B, int F, int nW,
+                              int nH, uint32_t drop_seed, float drop_p, const uint32_t* seed_base, hipStream_t st);
