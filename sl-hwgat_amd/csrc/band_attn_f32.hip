@@ -264,7 +264,9 @@ __global__ __launch_bounds__(256, MINW) void band_fwd_f32st_k(const float* __res
 #pragma unroll
                 for (int t = 0; t < 3; ++t) oacc = mul_cols(vw[t], e[t], oacc);
                 // lane (q = lr, g), reg r -> O[q][4g + r]; the row's 1 / sum is in this very lane
-                __builtin_nontemporal_store(oacc * inv, reinterpret_cast<f32x4v*>(ob + (int64_t)f * g.K * g.d + ooff));
+                // (plain stores: the four heads of a row arrive from four waves, and nontemporal ones, which the whole-row
+                //  stores of blk_attn_f32.hip gain from, cost these 64-byte pieces 8 % forward and 18 % backward)
+                *reinterpret_cast<f32x4v*>(ob + (int64_t)f * g.K * g.d + ooff) = oacc * inv;
             }
             kw[0] = kw[1]; kw[1] = kw[2];
             vw[0] = vw[1]; vw[1] = vw[2];
@@ -352,8 +354,8 @@ __global__ __launch_bounds__(256, MINW) void band_bwd_f32st_k(const float* __res
 
     auto store_key = [&](int f, const f32x4v& k, const f32x4v& v) {
         float* row = db + f * fs + roff;                         // lane (key = lr, g), reg r -> [key][4g + r]
-        __builtin_nontemporal_store(k * band_scale<HD>(), reinterpret_cast<f32x4v*>(row + g.d));
-        __builtin_nontemporal_store(v, reinterpret_cast<f32x4v*>(row + 2 * g.d));
+        *reinterpret_cast<f32x4v*>(row + g.d) = k * band_scale<HD>();
+        *reinterpret_cast<f32x4v*>(row + 2 * g.d) = v;
     };
     // transposed tile: lane (q = lr, g) wrote x[q][4g .. 4g+3]; lane (key = lr, g) reads x[q = 4g + r][key = lr]
     auto xpose3 = [&](const f32x4v (&x)[3], f32x4v (&y)[3]) {
@@ -413,7 +415,7 @@ __global__ __launch_bounds__(256, MINW) void band_bwd_f32st_k(const float* __res
                     f32x4v acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int t = 0; t < 3; ++t) acc = mul_cols(kw[t].kc, ds[t], acc);
-                    __builtin_nontemporal_store(acc * band_scale<HD>(), reinterpret_cast<f32x4v*>(db + f * fs + roff));
+                    *reinterpret_cast<f32x4v*>(db + f * fs + roff) = acc * band_scale<HD>();
                 }
                 // ---- lane = key joint lr, registers = query joints 4g + r
                 f32x4v p2[3], ds2[3];
