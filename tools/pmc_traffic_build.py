@@ -12,10 +12,10 @@ kind = sys.argv[1]
 files = sys.argv[2:6]
 SHAPES = {   # E elements of the launches tools/attn_pmc.py / tools/sibling_pmc.py make
     "win": {"hwgat_win_attn_fwd": ("win_attn_fwd_k", 64 * 128 * 80 * 128), "hwgat_win_attn_bwd": ("win_attn_bwd_k", 64 * 128 * 80 * 128)},
-    "sibling": {"hwgat_blk_attn_fwd": (("blk_attn_fwd_k", "blk_fwd_b16_k"), 64 * 128 * 29 * 128),
-                "hwgat_blk_attn_bwd": (("blk_attn_bwd_k", "blk_bwd_b16_k"), 64 * 128 * 29 * 128),
-                "hwgat_band_attn_fwd": (("band_attn_fwd_k", "band_fwd_st_k"), 64 * 128 * 64 * 128),
-                "hwgat_band_attn_bwd": (("band_attn_bwd_k", "band_bwd_st_k"), 64 * 128 * 64 * 128)},
+    "sibling": {"hwgat_blk_attn_fwd": (("blk_attn_fwd_k", "blk_fwd_b16_k", "blk_fwd_f32_k"), 64 * 128 * 29 * 128),
+                "hwgat_blk_attn_bwd": (("blk_attn_bwd_k", "blk_bwd_b16_k", "blk_bwd_f32_k"), 64 * 128 * 29 * 128),
+                "hwgat_band_attn_fwd": (("band_attn_fwd_k", "band_fwd_st_k", "band_fwd_f32st_k"), 64 * 128 * 64 * 128),
+                "hwgat_band_attn_bwd": (("band_attn_bwd_k", "band_bwd_st_k", "band_bwd_f32st_k"), 64 * 128 * 64 * 128)},
 }[kind]
 CAL_E = {"win": 64 * 128 * 80 * 128, "sibling": 64 * 128 * 64 * 128}[kind]
 
