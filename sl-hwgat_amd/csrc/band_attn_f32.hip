@@ -9,10 +9,10 @@
 // 10 (forward) and 28 (backward) memory instructions per frame and wave for 4 / 7 KB, and HBM held at 0.53 / 0.49 of its
 // rate.  Here, as in band_attn_bf16.hip:
 //
-//   workgroup = (clip, part window, frame segment, 4 neighbouring heads); wave w owns head 4 hg + w and walks the frames of
-//          the segment in order.  The workgroup fetches the q / k / v (/ dO) tiles of a frame TOGETHER: 16 token rows x
-//          (4 heads x 16 channels x 4 bytes) = whole 256-byte row pieces, by LDS-DMA (16 bytes per lane, 1 KB per
-//          instruction, no registers), one frame group ahead into a double buffer.
+//   workgroup = (clip, part window, frame segment, NHW = 8 (forward) or 4 neighbouring heads); wave w owns head NHW hg + w
+//          and walks the frames of the segment in order.  The workgroup fetches the q / k / v (/ dO) tiles of a frame
+//          TOGETHER: 16 token rows x (NHW heads x 16 channels x 4 bytes) = whole 512- / 256-byte row pieces, by LDS-DMA
+//          (16 bytes per lane, 1 KB per instruction, no registers), one frame group ahead into a double buffer.
 //   row operand  X[row = l&15][4 (l>>4) + 0..3] of the wave's head: one ds_read_b128 = the four k-steps of a head-dim
 //          contraction (S^T = K Q^T, dP^T = V dO^T).
 //   column operand X[row = 4 (l>>4) + r][l&15]: four ds_read_b32 from the SAME image = the A operand of the contractions over
@@ -38,9 +38,13 @@ typedef __attribute__((address_space(3))) float lds_f32;
 typedef __attribute__((address_space(3))) void* lds_void;
 
 constexpr int HD = 16;
-constexpr int RB = 4 * HD * 4;           // bytes per token row of a 4-head tile
-constexpr int TILE = 16 * RB;            // 4 KB
-constexpr int NI = TILE / 1024;          // DMA instructions per tile
+// a staged tile = 16 token rows x NHW heads (the waves of a workgroup) x 16 channels x 4 bytes
+template <int NHW> struct Tile {
+    static constexpr int RB = NHW * HD * 4;      // bytes per token row: 256 (4 heads) / 512 (8 heads: with d = 128 the whole q, k or v row)
+    static constexpr int BYTES = 16 * RB;        // 4 / 8 KB
+    static constexpr int NI = BYTES / 1024;      // DMA instructions per tile
+    static constexpr int RPI = 1024 / RB;        // token rows per DMA instruction
+};
 constexpr int XLD = 20;                  // floats per row of a transposing tile (16 + 4: conflict-free 16-byte writes and 4-byte column reads)
 constexpr int XTILE = 16 * XLD * 4;      // bytes
 constexpr float NEG_INF = -__builtin_inff();
@@ -72,14 +76,18 @@ __device__ __forceinline__ void wave_fence() {
 // chunk c (0..15) of tile row `row` sits in slot c ^ xrf(row): conflict-free ds_read_b128 of one chunk column of the 16 rows
 // and conflict-free ds_read_b32 of 16 consecutive channels of two rows 4 apart (see blk_attn_f32.hip)
 __device__ __forceinline__ int xrf(int row) { return (row & 7) | ((((row >> 2) ^ (row >> 3)) & 1) << 3); }
-// source byte offset (token rows of `row_bytes`) of this lane's 16 bytes in DMA instruction `ins` (4 rows) of a tile
-__device__ __forceinline__ uint32_t dma_src(int lane, int ins, uint32_t row_bytes) {
-    const int row = 4 * ins + (lane >> 4), cp = lane & 15;
+// source byte offset (token rows of `row_bytes`) of this lane's 16 bytes in DMA instruction `ins` (RPI rows) of a tile
+// (the swizzle touches the low four bits of the chunk index: with 512-byte rows a chunk stays in its 256-byte half, and the
+//  halves are a whole number of bank rows apart)
+template <int NHW> __device__ __forceinline__ uint32_t dma_src(int lane, int ins, uint32_t row_bytes) {
+    using TL = Tile<NHW>;
+    const int row = TL::RPI * ins + (lane * 16) / TL::RB, cp = ((lane * 16) % TL::RB) >> 4;
     return row * row_bytes + ((cp ^ xrf(row)) << 4);
 }
 
 // operands of head w from a staged tile.  Row: X[row = l&15][4g .. 4g+3]; column: X[row = 4g + r][l&15], r = 0..3
-struct Ops {
+template <int NHW> struct Ops {
+    static constexpr int RB = Tile<NHW>::RB;
     uint32_t row, col[4];
     __device__ __forceinline__ Ops(int lane, int w) {
         const int lr = lane & 15, g = lane >> 4;
@@ -151,15 +159,15 @@ __device__ __forceinline__ float band_exp(const f32x4v (&s)[3], const float (&bi
     return 1.0f / xg_sum(sum);
 }
 
-// unit = ((clip, window), segment, group of 4 heads): one workgroup; wave w of it owns head 4 hg + w
+// unit = ((clip, window), segment, group of NHW heads): one workgroup; wave w of it owns head NHW hg + w
 struct GroupF {
     int64_t tok0;          // token index of (clip, frame 0, first joint of the window)
     int hg, w, f0, f1;     // owned frames [f0, f1)
     int bw;                // clip * nW + window (see BandUnit)
 };
-__device__ __forceinline__ GroupF decode_group(const BandGeom& g, int blk) {
+__device__ __forceinline__ GroupF decode_group(const BandGeom& g, int blk, int nhw) {
     GroupF r;
-    const int n_hg = (g.nH + 3) >> 2;
+    const int n_hg = (g.nH + nhw - 1) / nhw;
     r.hg = blk % n_hg;
     int t = blk / n_hg;
     const int sgi = t % g.n_seg;
@@ -175,24 +183,26 @@ __device__ __forceinline__ GroupF decode_group(const BandGeom& g, int blk) {
 
 // =============================================================== forward
 // PF = frames per staged group (1 or 2): group = PF x (Q, K, V) tiles, double buffered
-template <int PF, int MINW, bool ADROP>
-__global__ __launch_bounds__(256, MINW) void band_fwd_f32st_k(const float* __restrict__ qkv, float* __restrict__ o,
+template <int NHW, int PF, int MINW, bool ADROP>
+__global__ __launch_bounds__(NHW * 64, MINW) void band_fwd_f32st_k(const float* __restrict__ qkv, float* __restrict__ o,
                                                               const uint64_t* __restrict__ maskrows, BandGeom g,
                                                               int64_t qkv_bytes, AttnDrop ad) {
     if constexpr (ADROP) ad.seed += seed_base_of(ad.base);
-    constexpr int WPF = 4 / PF;                                  // waves sharing the DMA work of one frame
-    constexpr int IPW = NI / WPF;                                // DMA instructions per tile and wave
-    static_assert(PF == 1 || PF == 2 || PF == 4, "frame group = 1, 2 or 4 frames");
+    using TL = Tile<NHW>;
+    constexpr int TILE = TL::BYTES;
+    constexpr int WPF = NHW / PF;                                // waves sharing the DMA work of one frame
+    constexpr int IPW = TL::NI / WPF;                            // DMA instructions per tile and wave
+    static_assert((PF == 1 || PF == 2 || PF == 4) && TL::NI % WPF == 0, "frame group = 1, 2 or 4 frames");
     constexpr int GROUP = PF * 3 * TILE;
     __shared__ __attribute__((aligned(1024))) char sm[2 * GROUP];    // [2][PF][Q K V][TILE]
     const int lane = threadIdx.x & 63, lr = lane & 15, gq = lane >> 4;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const GroupF un = decode_group(g, blockIdx.x);
-    const int head = 4 * un.hg + wib;
+    const GroupF un = decode_group(g, blockIdx.x, NHW);
+    const int head = NHW * un.hg + wib;
     const bool live = head < g.nH;                               // waves past the last head stage tiles but compute nothing
     const int hd_eff = min(head, g.nH - 1);
     const int64_t rs = 3 * (int64_t)g.d;                         // qkv row stride (elements)
-    const float* gb = qkv + un.tok0 * rs + 4 * un.hg * HD;       // the group's q columns of (frame 0, joint 0)
+    const float* gb = qkv + un.tok0 * rs + NHW * un.hg * HD;     // the group's q columns of (frame 0, joint 0)
     const float* qb = qkv + un.tok0 * rs + hd_eff * HD;          // this wave's head (prologue loads)
     float* ob = o + un.tok0 * (int64_t)g.d + hd_eff * HD;
     const int64_t fs = (int64_t)g.K * rs;                        // frame stride in qkv
@@ -201,15 +211,15 @@ __global__ __launch_bounds__(256, MINW) void band_fwd_f32st_k(const float* __res
     const uint32_t ooff = lr * (uint32_t)g.d + 4 * gq;           // ... and in o
     float bias[3][4];
     band_bias(maskrows[un.w * 16 + lr], gq, bias);
-    const Ops ops(lane, wib);
+    const Ops<NHW> ops(lane, wib);
 
     // DMA: resource = from the group's first byte to the end of the tensor (lanes past it read zeros: a last head group
-    // of fewer than 4 heads stages columns that belong to no head)
+    // of fewer than NHW heads stages columns that belong to no head)
     const int64_t left = qkv_bytes - ((const char*)gb - (const char*)qkv);
     const int span = (int)min(left, (int64_t)0x7fffffff);
     uint32_t voff[IPW];
 #pragma unroll
-    for (int j = 0; j < IPW; ++j) voff[j] = dma_src(lane, (wib % WPF) * IPW + j, (uint32_t)rs * 4);
+    for (int j = 0; j < IPW; ++j) voff[j] = dma_src<NHW>(lane, (wib % WPF) * IPW + j, (uint32_t)rs * 4);
     const uint32_t fs4 = (uint32_t)fs * 4, d4 = (uint32_t)g.d * 4;
     // wave w stages frame (w / WPF) of the group: Q of that frame, K and V of the frame after it
     auto stage = [&](int buf, int fb) {
@@ -284,15 +294,18 @@ __global__ __launch_bounds__(256, MINW) void band_bwd_f32st_k(const float* __res
                                                               const uint64_t* __restrict__ maskrows, BandGeom g,
                                                               int64_t qkv_bytes, int64_t do_bytes, AttnDrop ad) {
     if constexpr (ADROP) ad.seed += seed_base_of(ad.base);
-    constexpr int WPF = 4 / PF;
-    constexpr int IPW = NI / WPF;
+    constexpr int NHW = 4;                                       // (eight heads per workgroup would leave room for one workgroup per CU)
+    using TL = Tile<NHW>;
+    constexpr int TILE = TL::BYTES;
+    constexpr int WPF = NHW / PF;
+    constexpr int IPW = TL::NI / WPF;
     static_assert(PF == 1 || PF == 2, "frame group = 1 or 2 frames");
     constexpr int GROUP = PF * 4 * TILE;                         // one frame group: PF x (Q, K, V, dO)
     __shared__ __attribute__((aligned(1024))) char sm[2 * GROUP + 4 * 3 * XTILE];
     const int lane = threadIdx.x & 63, lr = lane & 15, gq = lane >> 4;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float* xt = reinterpret_cast<float*>(sm + 2 * GROUP + wib * (3 * XTILE));   // [3 key tiles][q][XLD]
-    const GroupF un = decode_group(g, blockIdx.x);
+    const GroupF un = decode_group(g, blockIdx.x, NHW);
     const int head = 4 * un.hg + wib;
     const bool live = head < g.nH;
     const int hd_eff = min(head, g.nH - 1);
@@ -306,7 +319,7 @@ __global__ __launch_bounds__(256, MINW) void band_bwd_f32st_k(const float* __res
     const uint32_t coff = 4 * gq * (uint32_t)rs + lr;            // ... column operand
     float bias[3][4];
     band_bias(maskrows[un.w * 16 + lr], gq, bias);
-    const Ops ops(lane, wib);
+    const Ops<NHW> ops(lane, wib);
     const int fa = max(un.f0 - 1, 0), fz = min(un.f1, g.F - 1);  // query frames fa .. fz (inclusive)
 
     const int span_q = (int)min(qkv_bytes - ((const char*)gqb - (const char*)qkv), (int64_t)0x7fffffff);
@@ -314,8 +327,8 @@ __global__ __launch_bounds__(256, MINW) void band_bwd_f32st_k(const float* __res
     uint32_t voff_q[IPW], voff_g[IPW];
 #pragma unroll
     for (int j = 0; j < IPW; ++j) {
-        voff_q[j] = dma_src(lane, (wib % WPF) * IPW + j, (uint32_t)rs * 4);
-        voff_g[j] = dma_src(lane, (wib % WPF) * IPW + j, (uint32_t)g.d * 4);
+        voff_q[j] = dma_src<NHW>(lane, (wib % WPF) * IPW + j, (uint32_t)rs * 4);
+        voff_g[j] = dma_src<NHW>(lane, (wib % WPF) * IPW + j, (uint32_t)g.d * 4);
     }
     const uint32_t fs4 = (uint32_t)fs * 4, gs4 = (uint32_t)gs * 4, d4 = (uint32_t)g.d * 4;
     // wave w stages frame (w / WPF) of the group: Q, dO of that frame, K and V of the frame after it
@@ -458,17 +471,21 @@ int hwgat_launch_band_fwd_f32(const void* qkv, void* o, const uint64_t* maskrows
     n_seg = (F + seg - 1) / seg;
     BandGeom g{F, nW * 16, nW, nH, nH * HD, seg, n_seg};
     const int64_t clip_bytes = (int64_t)F * nW * 16 * 3 * nH * HD * 4;
-    const int64_t blocks = (int64_t)B * nW * n_seg * ((nH + 3) / 4);
+    // eight heads per workgroup where the head count allows it: with d = 128 the tile rows are then whole q / k / v rows, the
+    // 16 joints of a window one contiguous 24 KB piece of qkv per frame (LABLOG 10.9)
+    const int nhw = lab_env("HWGAT_BAND_NHW") ? atoi(lab_env("HWGAT_BAND_NHW")) : (nH % 8 == 0 ? 8 : 4);
+    const int64_t blocks = (int64_t)B * nW * n_seg * ((nH + nhw - 1) / nhw);
     if (blocks > 0x7fffffff || clip_bytes > 0x7fffffff) return HWGAT_ESHAPE;
     const int64_t bytes = clip_bytes * B;
-    const int pf = lab_env("HWGAT_BAND_PF") ? atoi(lab_env("HWGAT_BAND_PF")) : 2;
-#define FWD(PF, MINW)                                                                                                              \
+    const int pf = lab_env("HWGAT_BAND_PF") ? atoi(lab_env("HWGAT_BAND_PF")) : (nhw == 8 ? 1 : 2);
+#define FWD(NHW, PF, MINW, MINWD)                                                                                                 \
     do {                                                                                                                          \
-        if (ad.p > 0.f) band_fwd_f32st_k<PF, MINW, true><<<(int)blocks, 256, 0, st>>>((const float*)qkv, (float*)o, maskrows, g, bytes, ad); \
-        else band_fwd_f32st_k<PF, MINW, false><<<(int)blocks, 256, 0, st>>>((const float*)qkv, (float*)o, maskrows, g, bytes, ad);  \
+        if (ad.p > 0.f) band_fwd_f32st_k<NHW, PF, MINWD, true><<<(int)blocks, NHW * 64, 0, st>>>((const float*)qkv, (float*)o, maskrows, g, bytes, ad); \
+        else band_fwd_f32st_k<NHW, PF, MINW, false><<<(int)blocks, NHW * 64, 0, st>>>((const float*)qkv, (float*)o, maskrows, g, bytes, ad);  \
     } while (0)
-    if (pf == 1) FWD(1, 4);
-    else FWD(2, 3);
+    if (nhw == 8) { if (pf == 2) FWD(8, 2, 2, 2); else FWD(8, 1, 6, 5); }    // 96 KB: one workgroup per CU / 48 KB: three
+    else if (pf == 1) FWD(4, 1, 4, 4);
+    else FWD(4, 2, 3, 3);
 #undef FWD
     HWGAT_LAUNCH_CHECK();
 }

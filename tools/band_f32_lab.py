@@ -45,10 +45,12 @@ if os.environ.get("HWGAT_BAND_F32") == "0":
     tf, tb = timed(fwd), timed(bwd)
     print(f"one wave per head (band_attn.hip): fwd {tf:7.1f} us {4 * E / tf / 1e6:5.2f} TB/s | bwd {tb:7.1f} us {7 * E / tb / 1e6:5.2f} TB/s")
     sys.exit(0)
-for pf, seg in ((1, 1), (2, 1), (1, 2), (2, 2), (1, 4), (2, 4), (1, 1), (2, 1), (1, 2), (2, 2)):
-    if True:
-        os.environ["HWGAT_BAND_PF"] = str(pf)
-        os.environ["HWGAT_BAND_FSEG"] = os.environ["HWGAT_BAND_BSEG"] = str(seg)
-        tf, tb = timed(fwd), timed(bwd)
-        print(f"frames per group {pf} segments {seg}: fwd {tf:7.1f} us {4 * E / tf / 1e6:5.2f} TB/s | bwd {tb:7.1f} us {7 * E / tb / 1e6:5.2f} TB/s", flush=True)
+for nhw, pf, seg in ((4, 2, 1), (4, 1, 1), (8, 1, 1), (8, 2, 1), (8, 1, 2), (4, 2, 1), (4, 1, 1), (8, 1, 1), (8, 2, 1), (8, 1, 2)):
+    os.environ["HWGAT_BAND_NHW"] = str(nhw)                      # (forward only: the backward pass keeps 4 heads per workgroup)
+    os.environ["HWGAT_BAND_PF"] = str(pf)
+    os.environ["HWGAT_BAND_FSEG"] = os.environ["HWGAT_BAND_BSEG"] = str(seg)
+    tf = timed(fwd)
+    os.environ["HWGAT_BAND_PF"] = str(min(pf, 2))
+    tb = timed(bwd)
+    print(f"heads per workgroup {nhw} frames per group {pf} segments {seg}: fwd {tf:7.1f} us {4 * E / tf / 1e6:5.2f} TB/s | bwd (4 heads) {tb:7.1f} us {7 * E / tb / 1e6:5.2f} TB/s", flush=True)
 subprocess.run([sys.executable, os.path.abspath(__file__), "old"], check=False)
