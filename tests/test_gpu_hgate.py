@@ -201,6 +201,18 @@ def test_full_size_properties():
     g2 = torch.randn(B, F, KJ, d, device=DEV, generator=g)
     HF.block_attention(x, bits, nH, True).backward(g2)
     assert x.grad[..., :d].abs().max() < 1e-3
+    # the fp32 kernels of blk_attn_f32.hip walk several units per persistent workgroup here (8 192 units, 768 / 512
+    # workgroups): the batch order does not change a bit of the gradients, and one clip equals the dense fp64 oracle
+    for shifted in (False, True):
+        x = qkv.clone().requires_grad_(True)
+        HF.block_attention(x, bits, nH, shifted).backward(g2)
+        perm = torch.randperm(B, device=DEV)
+        xp = qkv[perm].contiguous().requires_grad_(True)
+        HF.block_attention(xp, bits, nH, shifted).backward(g2[perm].contiguous())
+        assert torch.equal(xp.grad, x.grad[perm])
+        ref_in = qkv[5:6].cpu().double().requires_grad_(True)
+        _oracle_attn(ref_in, OH.block_adjacency(), nH, shifted).backward(g2[5:6].cpu().double())
+        assert rel_err(x.grad[5:6].cpu(), ref_in.grad) < F32_TOL
 
 
 def test_full_size_properties_bf16_backward():

@@ -45,7 +45,10 @@ def test_mfma16_operand_layout():
 
 
 @pytest.mark.parametrize("hd,nH,nW,F,B", [(16, 8, 2, 8, 2), (16, 2, 4, 37, 1), (32, 4, 3, 5, 2), (16, 4, 1, 1, 3),
-                                          (32, 2, 2, 2, 1), (16, 8, 4, 64, 1)])
+                                          (32, 2, 2, 2, 1), (16, 8, 4, 64, 1),
+                                          # head counts around the workgroup sizes of band_attn_f32.hip (8 heads forward where
+                                          # nH % 8 == 0, else 4; 4 backward): two full groups, three groups of four, a part group
+                                          (16, 16, 1, 9, 1), (16, 12, 2, 6, 1), (16, 6, 1, 20, 2)])
 def test_band_attention_fwd_bwd(hd, nH, nW, F, B):
     g = torch.Generator().manual_seed(hd + nW + F)
     d, K = nH * hd, nW * 16
@@ -192,6 +195,20 @@ def test_full_size_properties():
     g2 = torch.randn(B, F, K, d, device=DEV, generator=g)
     HF.band_attention(x, rows, nH).backward(g2)
     assert x.grad[..., :d].abs().max() < 1e-3
+    # the fp32 backward (band_attn_f32.hip): batch order and frame segmentation do not change a bit, and one window of one
+    # clip equals the dense fp64 oracle
+    x = qkv.clone().requires_grad_(True)
+    HF.band_attention(x, rows, nH).backward(g2)
+    perm = torch.randperm(B, device=DEV)
+    xp = qkv[perm].contiguous().requires_grad_(True)
+    HF.band_attention(xp, rows, nH).backward(g2[perm].contiguous())
+    assert torch.equal(xp.grad, x.grad[perm])
+    x1 = qkv[5:6].contiguous().requires_grad_(True)
+    HF.band_attention(x1, rows, nH).backward(g2[5:6].contiguous())
+    assert torch.equal(x1.grad, x.grad[5:6])
+    ref_in = qkv[7:8, :, :16].cpu().double().requires_grad_(True)
+    _oracle_attn(ref_in, OW.band_adjacency(F, 1), nH).backward(g2[7:8, :, :16].cpu().double())
+    assert rel_err(x.grad[7:8, :, :16].cpu(), ref_in.grad) < F32_TOL
 
 
 def test_full_size_properties_bf16():
