@@ -57,6 +57,23 @@ template <typename T, int NT> __device__ __forceinline__ void store_nt(T* p, con
     }
 }
 
+// streaming forms (every byte of q, k, v, dO is read once and every byte of o, dq, dk, dv written once by whole 256-byte
+// rows): nontemporal hints keep them out of the way of each other in L2
+template <typename T, int NT> __device__ __forceinline__ void load_nt_s(const T* p, float (&v)[NT]) {
+    if constexpr (sizeof(T) == 4 && NT == 4) { f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+    else if constexpr (sizeof(T) == 4 && NT == 2) { f32x2 t = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(p)); v[0] = t.x; v[1] = t.y; }
+    else load_nt<T, NT>(p, v);
+}
+template <typename T, int NT> __device__ __forceinline__ void store_nt_s(T* p, const float (&v)[NT]) {
+    if constexpr (sizeof(T) == 4 && NT == 4) { f32x4 t = {v[0], v[1], v[2], v[3]}; __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(p)); }
+    else if constexpr (sizeof(T) == 4 && NT == 2) { f32x2 t = {v[0], v[1]}; __builtin_nontemporal_store(t, reinterpret_cast<f32x2*>(p)); }
+    else store_nt<T, NT>(p, v);
+}
+template <typename T> __device__ __forceinline__ u32x4 load16_s(const T* p) {
+    if constexpr (sizeof(T) == 4) return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+    else return *reinterpret_cast<const u32x4*>(p);
+}
+
 // swap with the partner lane that holds the other 16 keys of the same query
 __device__ __forceinline__ float partner(float v) { return __shfl_xor(v, 32, 64); }
 

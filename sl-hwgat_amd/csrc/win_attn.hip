@@ -158,14 +158,14 @@ __global__ __launch_bounds__(256, 2) void win_attn_fwd_k(const T* __restrict__ q
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const T* p = qkv + tok_of(un, i * RPI + crow_l) * row3d + un.head * HD + ccol;
-            qr[i] = *reinterpret_cast<const u32x4*>(p);
-            kr[i] = *reinterpret_cast<const u32x4*>(p + g.d);
+            qr[i] = load16_s<T>(p);
+            kr[i] = load16_s<T>(p + g.d);
         }
         const T* vb = qkv + 2 * g.d + un.head * HD + lq * NT;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             if constexpr (B16) vn[r].load(vb + tok_of(un, crow(r, hh)) * row3d);
-            else load_nt<T, NT>(vb + tok_of(un, crow(r, hh)) * row3d, vn[r]);
+            else load_nt_s<T, NT>(vb + tok_of(un, crow(r, hh)) * row3d, vn[r]);
         }
     };
     Unit cur = decode_unit(g, u);
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256, 2) void win_attn_fwd_k(const T* __restrict__ q
             float ov[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) ov[nt] = oacc[nt][r];
-            store_nt<T, NT>(ob + tok_of(cur, crow(r, hh)) * (int64_t)g.d, ov);
+            store_nt_s<T, NT>(ob + tok_of(cur, crow(r, hh)) * (int64_t)g.d, ov);
         }
         lds_fence();
         cur = nxt;
@@ -285,10 +285,10 @@ __global__ __launch_bounds__(WAVES * 64, (sizeof(T) == 2 && HD <= 64) ? 2 : 1) v
         for (int i = 0; i < NLD; ++i) {
             const int64_t tk = tok_of(un, i * RPI + crow_l);
             const T* p = qkv + tk * row3d + un.head * HD + ccol;
-            qr[i] = *reinterpret_cast<const u32x4*>(p);
-            kr[i] = *reinterpret_cast<const u32x4*>(p + g.d);
-            vr[i] = *reinterpret_cast<const u32x4*>(p + 2 * g.d);
-            gr[i] = *reinterpret_cast<const u32x4*>(dO + tk * (int64_t)g.d + un.head * HD + ccol);
+            qr[i] = load16_s<T>(p);
+            kr[i] = load16_s<T>(p + g.d);
+            vr[i] = load16_s<T>(p + 2 * g.d);
+            gr[i] = load16_s<T>(dO + tk * (int64_t)g.d + un.head * HD + ccol);
         }
     };
     Unit cur = decode_unit(g, u);
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(WAVES * 64, (sizeof(T) == 2 && HD <= 64) ? 2 : 1) v
                 float ov[NT];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) ov[nt] = acc[nt][r] * mul;
-                store_nt<T, NT>(base + tok_of(cur, crow(r, hh)) * row3d, ov);
+                store_nt_s<T, NT>(base + tok_of(cur, crow(r, hh)) * row3d, ov);
             }
         };
         // dQ = scale * dS K        (A = dS in registers: lane = q)
