@@ -62,16 +62,27 @@ template <typename T, int NT> __device__ __forceinline__ void store_nt(T* p, con
 template <typename T, int NT> __device__ __forceinline__ void load_nt_s(const T* p, float (&v)[NT]) {
     if constexpr (sizeof(T) == 4 && NT == 4) { f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
     else if constexpr (sizeof(T) == 4 && NT == 2) { f32x2 t = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(p)); v[0] = t.x; v[1] = t.y; }
-    else load_nt<T, NT>(p, v);
+    else if constexpr (sizeof(T) == 2 && NT == 4) {
+        const u32x2 t = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p));
+        v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u); v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+    } else if constexpr (sizeof(T) == 2 && NT == 2) {
+        const uint32_t t = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(p));
+        v[0] = __uint_as_float(t << 16); v[1] = __uint_as_float(t & 0xffff0000u);
+    } else load_nt<T, NT>(p, v);
 }
 template <typename T, int NT> __device__ __forceinline__ void store_nt_s(T* p, const float (&v)[NT]) {
     if constexpr (sizeof(T) == 4 && NT == 4) { f32x4 t = {v[0], v[1], v[2], v[3]}; __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(p)); }
     else if constexpr (sizeof(T) == 4 && NT == 2) { f32x2 t = {v[0], v[1]}; __builtin_nontemporal_store(t, reinterpret_cast<f32x2*>(p)); }
-    else store_nt<T, NT>(p, v);
+    else if constexpr (sizeof(T) == 2 && NT == 4) {
+        const bf16x4 t = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+        __builtin_nontemporal_store(__builtin_bit_cast(u32x2, t), reinterpret_cast<u32x2*>(p));
+    } else if constexpr (sizeof(T) == 2 && NT == 2) {
+        const bf16x2 t = {(bf16_t)v[0], (bf16_t)v[1]};
+        __builtin_nontemporal_store(__builtin_bit_cast(uint32_t, t), reinterpret_cast<uint32_t*>(p));
+    } else store_nt<T, NT>(p, v);
 }
 template <typename T> __device__ __forceinline__ u32x4 load16_s(const T* p) {
-    if constexpr (sizeof(T) == 4) return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
-    else return *reinterpret_cast<const u32x4*>(p);
+    return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
 }
 
 // swap with the partner lane that holds the other 16 keys of the same query
@@ -188,6 +199,11 @@ template <int NT> struct brow {
         if constexpr (NT == 1) w[0] = *reinterpret_cast<const uint16_t*>(p);
         else if constexpr (NT == 2) w[0] = *reinterpret_cast<const uint32_t*>(p);
         else { const u32x2 t = *reinterpret_cast<const u32x2*>(p); w[0] = t.x; w[1] = t.y; }
+    }
+    __device__ __forceinline__ void load_s(const bf16_t* p) {       // streaming form (see load_nt_s)
+        if constexpr (NT == 1) w[0] = *reinterpret_cast<const uint16_t*>(p);
+        else if constexpr (NT == 2) w[0] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(p));
+        else { const u32x2 t = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p)); w[0] = t.x; w[1] = t.y; }
     }
 };
 // B operand of one k16 step for column tile nt: element j of the lane = rows[j], column nt of the lane's NT

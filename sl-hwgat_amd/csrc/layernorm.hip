@@ -21,15 +21,34 @@ template <int D> struct RowMap {
     static constexpr int CPL = NCH / LPR;                     // chunks per lane
 };
 
+typedef uint32_t u32x2w __attribute__((ext_vector_type(2)));
+// (nontemporal hints: every activation row is read once and written once per kernel)
 template <typename T, int D>
 __device__ __forceinline__ void load_row(const T* row, int sub, float (&v)[RowMap<D>::CPL][4]) {
 #pragma unroll
-    for (int c = 0; c < RowMap<D>::CPL; ++c) io<T>::load4(row + (c * RowMap<D>::LPR + sub) * 4, v[c]);
+    for (int c = 0; c < RowMap<D>::CPL; ++c) {
+        if constexpr (sizeof(T) == 4) {
+            const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(row + (c * RowMap<D>::LPR + sub) * 4));
+            v[c][0] = t.x; v[c][1] = t.y; v[c][2] = t.z; v[c][3] = t.w;
+        } else {
+            const u32x2w t = __builtin_nontemporal_load(reinterpret_cast<const u32x2w*>(row + (c * RowMap<D>::LPR + sub) * 4));
+            v[c][0] = __uint_as_float(t.x << 16); v[c][1] = __uint_as_float(t.x & 0xffff0000u);
+            v[c][2] = __uint_as_float(t.y << 16); v[c][3] = __uint_as_float(t.y & 0xffff0000u);
+        }
+    }
 }
 template <typename T, int D>
 __device__ __forceinline__ void store_row(T* row, int sub, const float (&v)[RowMap<D>::CPL][4]) {
 #pragma unroll
-    for (int c = 0; c < RowMap<D>::CPL; ++c) io<T>::store4(row + (c * RowMap<D>::LPR + sub) * 4, v[c]);
+    for (int c = 0; c < RowMap<D>::CPL; ++c) {
+        if constexpr (sizeof(T) == 4) {
+            const f32x4 t = {v[c][0], v[c][1], v[c][2], v[c][3]};
+            __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(row + (c * RowMap<D>::LPR + sub) * 4));
+        } else {
+            const bf16x4 t = {(bf16_t)v[c][0], (bf16_t)v[c][1], (bf16_t)v[c][2], (bf16_t)v[c][3]};
+            __builtin_nontemporal_store(__builtin_bit_cast(u32x2w, t), reinterpret_cast<u32x2w*>(row + (c * RowMap<D>::LPR + sub) * 4));
+        }
+    }
 }
 template <int D>
 __device__ __forceinline__ void load_vec(const float* p, int sub, float (&v)[RowMap<D>::CPL][4]) {

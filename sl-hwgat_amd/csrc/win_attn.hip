@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void win_attn_fwd_k(const T* __restrict__ q
         const T* vb = qkv + 2 * g.d + un.head * HD + lq * NT;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            if constexpr (B16) vn[r].load(vb + tok_of(un, crow(r, hh)) * row3d);
+            if constexpr (B16) vn[r].load_s(vb + tok_of(un, crow(r, hh)) * row3d);
             else load_nt_s<T, NT>(vb + tok_of(un, crow(r, hh)) * row3d, vn[r]);
         }
     };
@@ -424,10 +424,10 @@ __global__ __launch_bounds__(128, sizeof(T) == 2 ? 3 : 2) void win_attn_bwd_spli
         for (int i = 0; i < NLD; ++i) {
             const int64_t tk = tok_of(un, i * RPI + crow_l);
             const T* p = qkv + tk * row3d + un.head * HD + col0 + ccol;
-            qr[i] = *reinterpret_cast<const u32x4*>(p);
-            kr[i] = *reinterpret_cast<const u32x4*>(p + g.d);
-            vr[i] = *reinterpret_cast<const u32x4*>(p + 2 * g.d);
-            gr[i] = *reinterpret_cast<const u32x4*>(dO + tk * (int64_t)g.d + un.head * HD + col0 + ccol);
+            qr[i] = load16_s<T>(p);
+            kr[i] = load16_s<T>(p + g.d);
+            vr[i] = load16_s<T>(p + 2 * g.d);
+            gr[i] = load16_s<T>(dO + tk * (int64_t)g.d + un.head * HD + col0 + ccol);
         }
     };
     // partial 32x32 product of this wave + the other wave's, through the mailbox (callers place the barriers)
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(128, sizeof(T) == 2 ? 3 : 2) void win_attn_bwd_spli
                 float ov[NT];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) ov[nt] = acc[nt][r] * mul;
-                store_nt<T, NT>(base + tok_of(cur, crow(r, hh)) * row3d, ov);
+                store_nt_s<T, NT>(base + tok_of(cur, crow(r, hh)) * row3d, ov);
             }
         };
         tile_ay<HW, LDW>(ds, Ks, lq, hh, acc);                 // dQ[:, half] = scale * dS K[:, half]
