@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256, MINW) void band_fwd_st_k(const bf16_t* __restr
 #pragma unroll
             for (int j = 0; j < IPW; ++j)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void)(dst + t * St::TILE + j * 1024), 16, (int)voff[j],   // (the cast matters: without it clang drops the host stub of this kernel)
-                                                         (t ? fk : fq) * fs2 + t * d2, 0, 0);
+                                                         (t ? fk : fq) * fs2 + t * d2, 0, 2);
     };
     // this lane's read offsets inside a tile
     uint32_t r_row[NC], r_col[NC];
@@ -732,11 +732,11 @@ __global__ __launch_bounds__(256, MINW) void band_bwd_st_k(const bf16_t* __restr
 #pragma unroll
             for (int j = 0; j < IPW; ++j)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (lds_void)(dst + t * St::TILE + j * 1024), 16, (int)voff_q[j],
-                                                         (t ? fk : fq) * fs2 + t * d2, 0, 0);
+                                                         (t ? fk : fq) * fs2 + t * d2, 0, 2);
 #pragma unroll
         for (int j = 0; j < IPW; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_void)(dst + 3 * St::TILE + j * 1024), 16, (int)voff_g[j],
-                                                     fq * gs2, 0, 0);
+                                                     fq * gs2, 0, 2);
     };
     uint32_t r_row[NC], r_col[NC];
 #pragma unroll

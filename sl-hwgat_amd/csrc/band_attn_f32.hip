@@ -221,7 +221,8 @@ __global__ __launch_bounds__(NHW * 64, MINW) void band_fwd_f32st_k(const float* 
 #pragma unroll
     for (int j = 0; j < IPW; ++j) voff[j] = dma_src<NHW>(lane, (wib % WPF) * IPW + j, (uint32_t)rs * 4);
     const uint32_t fs4 = (uint32_t)fs * 4, d4 = (uint32_t)g.d * 4;
-    // wave w stages frame (w / WPF) of the group: Q of that frame, K and V of the frame after it
+    // wave w stages frame (w / WPF) of the group: Q of that frame, K and V of the frame after it (nontemporal loads, aux = 2:
+    // + 3 % here, + 8 % in the bf16 kernel, + 30 % in the bf16 block-attention forward; the backward kernels are indifferent)
     auto stage = [&](int buf, int fb) {
         const int i = wib / WPF;
         const int fq = min(fb + i, g.F - 1), fk = min(fb + i + 1, g.F - 1);    // clamped: such tiles are masked or unused
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(NHW * 64, MINW) void band_fwd_f32st_k(const float* 
 #pragma unroll
             for (int j = 0; j < IPW; ++j)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void)(dst + t * TILE + j * 1024), 16, (int)voff[j],
-                                                         (t ? fk : fq) * fs4 + t * d4, 0, 0);
+                                                         (t ? fk : fq) * fs4 + t * d4, 0, 2);
     };
 
     stage(0, un.f0);

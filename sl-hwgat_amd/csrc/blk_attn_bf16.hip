@@ -46,15 +46,15 @@ __device__ __forceinline__ void stage_unit(char* sm, const bf16_t* qkv, const bf
         const uint32_t frame_rel = (uint32_t)((ins >> 2 ? un.base[1] : un.base[0]) - t0);
         const uint32_t src = (uint32_t)(cp ^ xr(row)) << 4;
         const int vq = (int)((frame_rel + joint) * rs2 + src);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (lds_void)(sm + ins * 1024), 16, vq, 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (lds_void)(sm + IMG + ins * 1024), 16, vq, (int)d2, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (lds_void)(sm + 2 * IMG + ins * 1024), 16, vq, (int)(2 * d2), 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (lds_void)(sm + ins * 1024), 16, vq, 0, 0, 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (lds_void)(sm + IMG + ins * 1024), 16, vq, (int)d2, 0, 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (lds_void)(sm + 2 * IMG + ins * 1024), 16, vq, (int)(2 * d2), 0, 2);
         if constexpr (NIMG == 4) {
             const bf16_t* gb = dO + t0 * (int64_t)g.d + un.head * HD;
             const int span_g = (int)min(do_bytes - ((const char*)gb - (const char*)dO), (int64_t)0x7fffffff);
             const auto rg = __builtin_amdgcn_make_buffer_rsrc((void*)gb, 0, span_g, 0x00020000);
             const int vg = (int)((frame_rel + joint) * d2 + src);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_void)(sm + 3 * IMG + ins * 1024), 16, vg, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (lds_void)(sm + 3 * IMG + ins * 1024), 16, vg, 0, 0, 2);
         }
     }
 }
