@@ -55,6 +55,15 @@ __device__ __forceinline__ void pin() {
 // (STAT: 0 = plain epilogue, 1 = + row statistics, 2 = + row statistics and the merged store: separate instantiations,
 //  because the merged store's index arithmetic would otherwise sit, as a branch per pass, in every epilogue;
 //  3 = X_LNFOLD, the row-affine epilogue of a folded LayerNorm -- fused_ops.h)
+#ifdef HWGAT_LAB
+// lab build only: s_memtime at the start and the end of every workgroup, [workgroup][2], through a pointer set with
+// hwgat_lab_nt256_stamps (tools/nt256_clock.py: the shader clock the chip holds under this kernel)
+__device__ unsigned long long* g_nt256_stamps = nullptr;
+#define NT256_STAMP(i) do { if (g_nt256_stamps && threadIdx.x == 0) g_nt256_stamps[blockIdx.x * 2 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define NT256_STAMP(i) do {} while (0)
+#endif
+
 template <int PRO, int EPI, int STAT = 0>
 __global__ __launch_bounds__(256, 1) void gemm_nt256_k(NtArgs p) {
     HWGAT_RESOLVE_SEEDS2(p);
@@ -183,6 +192,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_k(NtArgs p) {
     int64_t m0; int n0;
     tile_origin(t, m0, n0);
     set_tile(m0, n0);
+    NT256_STAMP(0);
     issue(0);
     commit(0, m0, 0);
     __syncthreads();
@@ -316,6 +326,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256_k(NtArgs p) {
         if (t >= n_tiles) break;
         m0 = mn; n0 = nn;
     }
+    NT256_STAMP(1);
 }
 
 template <int PRO>
@@ -366,3 +377,9 @@ int hwgat_launch_nt256(const NtArgs& a, int pro, int epi, hipStream_t st) {
         default: return HWGAT_EINVAL;
     }
 }
+
+#ifdef HWGAT_LAB
+extern "C" int hwgat_lab_nt256_stamps(void* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_nt256_stamps), &buf, sizeof(buf)) == hipSuccess ? 0 : HWGAT_EINVAL;
+}
+#endif
